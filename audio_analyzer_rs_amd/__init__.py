@@ -1,0 +1,18 @@
+"""MI355X-native STFT / spectrogram hot path — drop-in for audio-analyzer-rs's
+`FftProcessor` + frame loop (src/dsp/fft.rs, src/audio_io/stft.rs:273-318,
+src/analysis/onset.rs:244-272).
+
+Everything computes through libaa_stft.so (HIP kernels for gfx950 behind the C ABI of
+include/aa_stft.h).  Importing the package does not need a GPU; creating a plan does.
+"""
+from . import _lib
+from ._lib import AaError, LIB_PATH  # noqa: F401
+from .fft import FftProcessor, hann_window  # noqa: F401
+from .stft import Stft, StftStream  # noqa: F401
+from .sharding import ShardPlan, gather_rows, scatter_samples, shard_frames, shard_samples  # noqa: F401
+from . import signals  # noqa: F401
+
+
+def load_library():
+    """Load (and return) the ctypes handle of libaa_stft.so; raises if it is not built."""
+    return _lib.load()

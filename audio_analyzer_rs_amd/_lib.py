@@ -1,0 +1,134 @@
+"""ctypes loader for libaa_stft.so (the C ABI declared in include/aa_stft.h).
+
+The library is the product: if it is missing the package fails loudly — there is
+no CPU or PyTorch fallback for any compute entry point.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaa_stft.so")
+
+AA_OK = 0
+AA_ERR_ARG = -1
+AA_ERR_LEN = -2
+AA_ERR_HIP = -3
+AA_ERR_NOMEM = -4
+AA_ERR_UNSUPPORTED = -5
+AA_ERR_NCCL = -6
+
+AA_WINDOW_HANN_PERIODIC = 0
+AA_WINDOW_RECT = 1
+AA_WINDOW_CUSTOM = 2
+
+AA_OUT_COMPLEX = 0
+AA_OUT_MAG = 1
+AA_OUT_POWER = 2
+AA_OUT_LOGPOWER = 3
+AA_OUT_LOGMEL = 4
+AA_OUT_MFCC = 5
+
+OUTPUT_KINDS = {
+    "complex": AA_OUT_COMPLEX,
+    "mag": AA_OUT_MAG,
+    "power": AA_OUT_POWER,
+    "logpower": AA_OUT_LOGPOWER,
+    "logmel": AA_OUT_LOGMEL,
+    "mfcc": AA_OUT_MFCC,
+}
+WINDOW_KINDS = {"hann": AA_WINDOW_HANN_PERIODIC, "rect": AA_WINDOW_RECT, "custom": AA_WINDOW_CUSTOM}
+
+
+class AaError(RuntimeError):
+    """A non-zero status from libaa_stft.so (the reference panics instead: fft.rs:69)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libaa_stft status {code}: {message}")
+        self.code = code
+
+
+class StftConfig(ctypes.Structure):
+    """Mirror of `aa_stft_config` (include/aa_stft.h)."""
+
+    _fields_ = [
+        ("n_fft", ctypes.c_int32),
+        ("hop", ctypes.c_int32),
+        ("window", ctypes.c_int32),
+        ("output", ctypes.c_int32),
+        ("sample_rate", ctypes.c_int32),
+        ("n_mels", ctypes.c_int32),
+        ("n_mfcc", ctypes.c_int32),
+        ("fmin", ctypes.c_float),
+        ("fmax", ctypes.c_float),
+        ("log_floor", ctypes.c_float),
+    ]
+
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); this is also the export list the CPU test checks
+# against include/aa_stft.h.
+SIGNATURES = {
+    "aa_last_error": (ctypes.c_char_p, []),
+    "aa_abi_version": (ctypes.c_int, []),
+    "aa_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "aa_hann_window": (ctypes.c_int, [ctypes.c_int, _f32p]),
+    "aa_fft_create": (ctypes.c_int, [ctypes.c_int, _vpp]),
+    "aa_fft_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_fft_len": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_fft_forward": (ctypes.c_int, [ctypes.c_void_p, _f32p, _f32p]),
+    "aa_fft_inverse": (ctypes.c_int, [ctypes.c_void_p, _f32p, _f32p]),
+    "aa_fft_forward_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_int64, ctypes.c_void_p]),
+    "aa_fft_inverse_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_int64, ctypes.c_void_p]),
+    "aa_stft_plan_create": (ctypes.c_int, [ctypes.POINTER(StftConfig), _f32p, _vpp]),
+    "aa_stft_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_stft_num_frames": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
+    "aa_stft_out_cols": (ctypes.c_int32, [ctypes.c_void_p]),
+    "aa_stft_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "aa_stft_execute_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_void_p]),
+    "aa_stft_execute_host": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int64, _f32p]),
+    "aa_shard_frames": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]),
+    "aa_shard_samples": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_int32, _i64p, _i64p]),
+    "aa_stream_create": (ctypes.c_int, [ctypes.POINTER(StftConfig), ctypes.c_int32, _vpp]),
+    "aa_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_stream_push": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int32, _f32p, _i64p,
+                                      ctypes.c_int64, _i64p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libaa_stft.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C audio_analyzer_rs_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != AA_OK:
+        msg = load().aa_last_error()
+        raise AaError(status, msg.decode("utf-8", "replace") if msg else "")
+    return status
+
+
+def f32_ptr(arr):
+    return arr.ctypes.data_as(_f32p)

@@ -1,0 +1,611 @@
+// C-ABI layer of libaa_stft.so: plans, tables, workspaces, error reporting.
+// Public contract and the reference lines each entry replaces: include/aa_stft.h.
+#include "../../include/aa_stft.h"
+#include "aa_internal.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define AA_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(AA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                 \
+    } while (0)
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
+            ok = true;
+    }
+    ~DeviceGuard()
+    {
+        if (ok && prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// Twiddle tables shared by the generic kernels: W_m^q (q < m/2 for powers of two,
+// q < m otherwise) and the split table W_n^k, k <= m/2.  f64 evaluation, f32 storage.
+struct FftTables {
+    int n = 0;
+    bool pow2 = false;
+    float *tw_m = nullptr;      // device
+    float *tw_split = nullptr;  // device
+};
+
+int build_fft_tables(int n, FftTables *t)
+{
+    const int m = n / 2;
+    t->n = n;
+    t->pow2 = is_pow2(n);
+    const int ntw = t->pow2 ? (m / 2 > 0 ? m / 2 : 1) : m;
+    std::vector<float> a(2 * (size_t)ntw), b(2 * (size_t)(m / 2 + 1));
+    for (int q = 0; q < ntw; ++q) {
+        double ang = -2.0 * kPi * (double)q / (double)m;
+        a[2 * q] = (float)std::cos(ang);
+        a[2 * q + 1] = (float)std::sin(ang);
+    }
+    for (int k = 0; k <= m / 2; ++k) {
+        double ang = -2.0 * kPi * (double)k / (double)n;
+        b[2 * k] = (float)std::cos(ang);
+        b[2 * k + 1] = (float)std::sin(ang);
+    }
+    AA_HIP(hipMalloc(&t->tw_m, a.size() * sizeof(float)));
+    AA_HIP(hipMalloc(&t->tw_split, b.size() * sizeof(float)));
+    AA_HIP(hipMemcpy(t->tw_m, a.data(), a.size() * sizeof(float), hipMemcpyHostToDevice));
+    AA_HIP(hipMemcpy(t->tw_split, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    return AA_OK;
+}
+
+void free_fft_tables(FftTables *t)
+{
+    if (t->tw_m)
+        (void)hipFree(t->tw_m);
+    if (t->tw_split)
+        (void)hipFree(t->tw_split);
+    t->tw_m = t->tw_split = nullptr;
+}
+
+int check_len(int len)
+{
+    if (len < 4 || (len & 1))
+        return fail(AA_ERR_LEN, "FFT length %d: must be even and >= 4", len);
+    if (len > 8192)
+        return fail(AA_ERR_LEN, "FFT length %d: this build supports lengths up to 8192", len);
+    return AA_OK;
+}
+
+void hann_f32(int n, float *w)
+{
+    // src/audio_io/stft.rs:641-648 — all-f32 periodic Hann.
+    const float pi_f32 = 3.14159265358979323846f;
+    for (int i = 0; i < n; ++i) {
+        float x = (float)i / (float)n;
+        float arg = 2.0f * pi_f32 * x;
+        w[i] = 0.5f - 0.5f * cosf(arg);
+    }
+}
+
+// Per-lane constants of the wave-per-frame 1024 kernel, [kWave1024Rows][64]:
+//   rows  0..15  0.5 * w[2*(64 j + n2) + c]           (row 2j + c),  n2 = 8*(lane&7) + (lane>>3)
+//   rows 16..29  W_512^(n2 k)  re,im   k = 1..7        (pass A twiddles)
+//   rows 30..43  W_64^(b k)    re,im   k = 1..7, b = lane>>3   (pass B twiddles)
+//   rows 44..51  (-sin t, -cos t), t = 2 pi (lane + 64 j)/1024, j = 0..3   (= -i W_1024^k)
+void build_wave1024_table(const float *window, std::vector<float> *tab)
+{
+    tab->assign((size_t)aa::kWave1024Rows * 64, 0.0f);
+    float *T = tab->data();
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n2 = 8 * (lane & 7) + (lane >> 3);
+        const int b = lane >> 3;
+        for (int j = 0; j < 8; ++j)
+            for (int c = 0; c < 2; ++c)
+                T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (64 * j + n2) + c];
+        for (int k = 1; k < 8; ++k) {
+            double aA = -2.0 * kPi * (double)(n2 * k) / 512.0;
+            T[(16 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aA);
+            T[(17 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aA);
+            double aB = -2.0 * kPi * (double)(b * k) / 64.0;
+            T[(30 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aB);
+            T[(31 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aB);
+        }
+        for (int j = 0; j < 4; ++j) {
+            double th = 2.0 * kPi * (double)(lane + 64 * j) / 1024.0;
+            T[(44 + 2 * j) * 64 + lane] = (float)(-std::sin(th));
+            T[(45 + 2 * j) * 64 + lane] = (float)(-std::cos(th));
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- plan structs --
+struct aa_fft_plan {
+    int len = 0;
+    int device = 0;
+    FftTables tabs;
+    float *d_in = nullptr;   // one frame
+    float *d_out = nullptr;  // one spectrum
+};
+
+struct aa_stft_plan {
+    aa_stft_config cfg{};
+    int device = 0;
+    int out_cols = 0;
+    float log_floor = 1e-10f;
+    std::vector<float> window_host;
+    float *d_window = nullptr;
+    FftTables tabs;
+    // wave1024 path
+    bool wave1024 = false;
+    int frames_per_wg = 16;
+    float *d_w1024_tab = nullptr;
+    // host-execute workspace
+    float *d_ws_in = nullptr;
+    size_t ws_in_floats = 0;
+    float *d_ws_out = nullptr;
+    size_t ws_out_floats = 0;
+};
+
+extern "C" {
+
+const char *aa_last_error(void) { return g_err; }
+int aa_abi_version(void) { return AA_ABI_VERSION; }
+
+int aa_device_count(int *count)
+{
+    if (!count)
+        return fail(AA_ERR_ARG, "aa_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(AA_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return AA_OK;
+}
+
+int aa_hann_window(int n, float *out_host)
+{
+    if (n <= 0 || !out_host)
+        return fail(AA_ERR_ARG, "aa_hann_window: n=%d out=%p", n, (void *)out_host);
+    hann_f32(n, out_host);
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ FftProcessor --
+int aa_fft_create(int len, aa_fft_plan **out_plan)
+{
+    if (!out_plan)
+        return fail(AA_ERR_ARG, "aa_fft_create: out_plan is NULL");
+    *out_plan = nullptr;
+    int rc = check_len(len);
+    if (rc != AA_OK)
+        return rc;
+    aa_fft_plan *p = new (std::nothrow) aa_fft_plan();
+    if (!p)
+        return fail(AA_ERR_NOMEM, "aa_fft_create: out of host memory");
+    p->len = len;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(AA_ERR_HIP, "hipGetDevice: %s (no usable HIP device; there is no CPU fallback)",
+                    hipGetErrorString(e));
+    }
+    rc = build_fft_tables(len, &p->tabs);
+    if (rc == AA_OK) {
+        hipError_t e1 = hipMalloc(&p->d_in, sizeof(float) * (size_t)(len + 2));
+        hipError_t e2 = hipMalloc(&p->d_out, sizeof(float) * (size_t)(len + 2));
+        if (e1 != hipSuccess || e2 != hipSuccess)
+            rc = fail(AA_ERR_HIP, "hipMalloc(frame buffers): %s",
+                      hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+    if (rc != AA_OK) {
+        aa_fft_destroy(p);
+        return rc;
+    }
+    *out_plan = p;
+    return AA_OK;
+}
+
+int aa_fft_destroy(aa_fft_plan *p)
+{
+    if (!p)
+        return AA_OK;
+    DeviceGuard g(p->device);
+    free_fft_tables(&p->tabs);
+    if (p->d_in)
+        (void)hipFree(p->d_in);
+    if (p->d_out)
+        (void)hipFree(p->d_out);
+    delete p;
+    return AA_OK;
+}
+
+int aa_fft_len(const aa_fft_plan *p) { return p ? p->len : 0; }
+
+int aa_fft_forward_batch_device(aa_fft_plan *p, const float *in_dev, float *out_dev, int64_t batch,
+                                void *stream)
+{
+    if (!p || !in_dev || !out_dev || batch < 0)
+        return fail(AA_ERR_ARG, "aa_fft_forward_batch_device: bad argument");
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    AA_HIP(aa::launch_generic_forward(p->tabs.pow2, aa::kComplex, in_dev, out_dev, nullptr,
+                                      p->tabs.tw_m, p->tabs.tw_split, p->len, 0, batch, p->len,
+                                      1e-10f, (hipStream_t)stream));
+    return AA_OK;
+}
+
+int aa_fft_inverse_batch_device(aa_fft_plan *p, const float *spec_dev, float *out_dev,
+                                int64_t batch, void *stream)
+{
+    if (!p || !spec_dev || !out_dev || batch < 0)
+        return fail(AA_ERR_ARG, "aa_fft_inverse_batch_device: bad argument");
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    AA_HIP(aa::launch_generic_inverse(p->tabs.pow2, spec_dev, out_dev, p->tabs.tw_m,
+                                      p->tabs.tw_split, p->len, batch, (hipStream_t)stream));
+    return AA_OK;
+}
+
+int aa_fft_forward(aa_fft_plan *p, const float *in_host, float *out_host)
+{
+    if (!p || !in_host || !out_host)
+        return fail(AA_ERR_ARG, "aa_fft_forward: NULL argument");
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    const size_t nin = sizeof(float) * (size_t)p->len, nout = sizeof(float) * (size_t)(p->len + 2);
+    AA_HIP(hipMemcpyAsync(p->d_in, in_host, nin, hipMemcpyHostToDevice, nullptr));
+    int rc = aa_fft_forward_batch_device(p, p->d_in, p->d_out, 1, nullptr);
+    if (rc != AA_OK)
+        return rc;
+    AA_HIP(hipMemcpyAsync(out_host, p->d_out, nout, hipMemcpyDeviceToHost, nullptr));
+    AA_HIP(hipStreamSynchronize(nullptr));
+    return AA_OK;
+}
+
+int aa_fft_inverse(aa_fft_plan *p, const float *spec_host, float *out_host)
+{
+    if (!p || !spec_host || !out_host)
+        return fail(AA_ERR_ARG, "aa_fft_inverse: NULL argument");
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    const size_t nspec = sizeof(float) * (size_t)(p->len + 2), nout = sizeof(float) * (size_t)p->len;
+    AA_HIP(hipMemcpyAsync(p->d_out, spec_host, nspec, hipMemcpyHostToDevice, nullptr));
+    int rc = aa_fft_inverse_batch_device(p, p->d_out, p->d_in, 1, nullptr);
+    if (rc != AA_OK)
+        return rc;
+    AA_HIP(hipMemcpyAsync(out_host, p->d_in, nout, hipMemcpyDeviceToHost, nullptr));
+    AA_HIP(hipStreamSynchronize(nullptr));
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------ batched STFT --
+int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_host,
+                        aa_stft_plan **out_plan)
+{
+    if (!cfg || !out_plan)
+        return fail(AA_ERR_ARG, "aa_stft_plan_create: NULL argument");
+    *out_plan = nullptr;
+    int rc = check_len(cfg->n_fft);
+    if (rc != AA_OK)
+        return rc;
+    if (cfg->hop <= 0)
+        return fail(AA_ERR_ARG, "hop must be positive (got %d)", cfg->hop);
+    if (cfg->window < AA_WINDOW_HANN_PERIODIC || cfg->window > AA_WINDOW_CUSTOM)
+        return fail(AA_ERR_ARG, "unknown window kind %d", cfg->window);
+    if (cfg->window == AA_WINDOW_CUSTOM && !custom_window_host)
+        return fail(AA_ERR_ARG, "AA_WINDOW_CUSTOM needs custom_window_host");
+    if (cfg->output < AA_OUT_COMPLEX || cfg->output > AA_OUT_MFCC)
+        return fail(AA_ERR_ARG, "unknown output kind %d", cfg->output);
+    if (cfg->output == AA_OUT_LOGMEL || cfg->output == AA_OUT_MFCC)
+        return fail(AA_ERR_UNSUPPORTED, "mel / MFCC outputs are not built yet");
+
+    aa_stft_plan *p = new (std::nothrow) aa_stft_plan();
+    if (!p)
+        return fail(AA_ERR_NOMEM, "aa_stft_plan_create: out of host memory");
+    p->cfg = *cfg;
+    p->log_floor = cfg->log_floor > 0.0f ? cfg->log_floor : 1e-10f;
+    const int nb = cfg->n_fft / 2 + 1;
+    p->out_cols = cfg->output == AA_OUT_COMPLEX ? 2 * nb : nb;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(AA_ERR_HIP, "hipGetDevice: %s (no usable HIP device; there is no CPU fallback)",
+                    hipGetErrorString(e));
+    }
+    p->window_host.resize(cfg->n_fft);
+    if (cfg->window == AA_WINDOW_HANN_PERIODIC)
+        hann_f32(cfg->n_fft, p->window_host.data());
+    else if (cfg->window == AA_WINDOW_RECT)
+        std::fill(p->window_host.begin(), p->window_host.end(), 1.0f);
+    else
+        std::memcpy(p->window_host.data(), custom_window_host, sizeof(float) * cfg->n_fft);
+
+    auto setup = [&]() -> int {
+        AA_HIP(hipMalloc(&p->d_window, sizeof(float) * cfg->n_fft));
+        AA_HIP(hipMemcpy(p->d_window, p->window_host.data(), sizeof(float) * cfg->n_fft,
+                         hipMemcpyHostToDevice));
+        int r = build_fft_tables(cfg->n_fft, &p->tabs);
+        if (r != AA_OK)
+            return r;
+        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
+            // frames per workgroup: as many as fit the LDS budget, capped by the tunable.
+            int want = 16;
+            if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))
+                want = std::atoi(s) > 0 ? std::atoi(s) : want;
+            const int64_t budget_dwords = 16384 - 4 * aa::kWave1024XchDwords;  // 64 KiB total
+            int fpw = 1;
+            while (fpw < want &&
+                   aa::wave1024_stage_dwords(fpw * cfg->hop + 1024) <= budget_dwords)
+                ++fpw;
+            if (aa::wave1024_stage_dwords((fpw - 1) * cfg->hop + 1024) <= budget_dwords) {
+                std::vector<float> tab;
+                build_wave1024_table(p->window_host.data(), &tab);
+                AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+                p->frames_per_wg = fpw;
+                p->wave1024 = true;
+            }
+        }
+        return AA_OK;
+    };
+    rc = setup();
+    if (rc != AA_OK) {
+        aa_stft_plan_destroy(p);
+        return rc;
+    }
+    *out_plan = p;
+    return AA_OK;
+}
+
+int aa_stft_plan_destroy(aa_stft_plan *p)
+{
+    if (!p)
+        return AA_OK;
+    DeviceGuard g(p->device);
+    free_fft_tables(&p->tabs);
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out};
+    for (float *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    delete p;
+    return AA_OK;
+}
+
+int64_t aa_stft_num_frames(const aa_stft_plan *p, int64_t n_samples)
+{
+    if (!p || n_samples < p->cfg.n_fft)
+        return 0;
+    return (n_samples - p->cfg.n_fft) / p->cfg.hop + 1;
+}
+
+int32_t aa_stft_out_cols(const aa_stft_plan *p) { return p ? p->out_cols : 0; }
+
+const char *aa_stft_kernel_name(const aa_stft_plan *p)
+{
+    if (!p)
+        return "";
+    if (p->wave1024)
+        return "wave1024";
+    return p->tabs.pow2 ? "lds_radix2" : "dft";
+}
+
+int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
+                           int64_t frame_begin, int64_t frame_end, float *out_dev, void *stream)
+{
+    if (!p || !samples_dev || !out_dev)
+        return fail(AA_ERR_ARG, "aa_stft_execute_device: NULL argument");
+    const int64_t total = aa_stft_num_frames(p, n_samples);
+    if (frame_begin < 0 || frame_end < frame_begin || frame_end > total)
+        return fail(AA_ERR_ARG, "frame range [%lld, %lld) outside [0, %lld)", (long long)frame_begin,
+                    (long long)frame_end, (long long)total);
+    const int64_t nf = frame_end - frame_begin;
+    if (nf == 0)
+        return AA_OK;
+    if (nf > 0x7fffffffLL)
+        return fail(AA_ERR_ARG, "more than 2^31-1 frames in one call");
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const float *first = samples_dev + frame_begin * (int64_t)p->cfg.hop;
+    if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+        AA_HIP(aa::launch_wave1024(p->cfg.output, samples_dev, out_dev, p->d_w1024_tab, frame_begin,
+                                   nf, p->cfg.hop, p->frames_per_wg, p->log_floor, st));
+    } else {
+        AA_HIP(aa::launch_generic_forward(p->tabs.pow2, p->cfg.output, samples_dev, out_dev,
+                                          p->d_window, p->tabs.tw_m, p->tabs.tw_split, p->cfg.n_fft,
+                                          frame_begin, nf, p->cfg.hop, p->log_floor, st));
+    }
+    return AA_OK;
+}
+
+static int grow(float **buf, size_t *have, size_t want)
+{
+    if (*have >= want)
+        return AA_OK;
+    if (*buf)
+        (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    AA_HIP(hipMalloc(buf, want * sizeof(float)));
+    *have = want;
+    return AA_OK;
+}
+
+int aa_stft_execute_host(aa_stft_plan *p, const float *samples_host, int64_t n_samples,
+                         float *out_host)
+{
+    if (!p || !samples_host || !out_host || n_samples < 0)
+        return fail(AA_ERR_ARG, "aa_stft_execute_host: bad argument");
+    const int64_t nf = aa_stft_num_frames(p, n_samples);
+    if (nf == 0)
+        return AA_OK;
+    DeviceGuard g(p->device);
+    if (!g.ok)
+        return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    int rc = grow(&p->d_ws_in, &p->ws_in_floats, (size_t)n_samples);
+    if (rc != AA_OK)
+        return rc;
+    rc = grow(&p->d_ws_out, &p->ws_out_floats, (size_t)nf * p->out_cols);
+    if (rc != AA_OK)
+        return rc;
+    AA_HIP(hipMemcpyAsync(p->d_ws_in, samples_host, sizeof(float) * (size_t)n_samples,
+                          hipMemcpyHostToDevice, nullptr));
+    rc = aa_stft_execute_device(p, p->d_ws_in, n_samples, 0, nf, p->d_ws_out, nullptr);
+    if (rc != AA_OK)
+        return rc;
+    AA_HIP(hipMemcpyAsync(out_host, p->d_ws_out, sizeof(float) * (size_t)nf * p->out_cols,
+                          hipMemcpyDeviceToHost, nullptr));
+    AA_HIP(hipStreamSynchronize(nullptr));
+    return AA_OK;
+}
+
+// ---------------------------------------------------------------------- sharding --
+int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *f0, int64_t *f1)
+{
+    if (!f0 || !f1 || world <= 0 || rank < 0 || rank >= world || total_frames < 0)
+        return fail(AA_ERR_ARG, "aa_shard_frames: bad argument");
+    // 128-bit intermediate: rank * total can exceed 2^63 only for absurd sizes, but be exact.
+    *f0 = (int64_t)(((__int128)total_frames * rank) / world);
+    *f1 = (int64_t)(((__int128)total_frames * (rank + 1)) / world);
+    return AA_OK;
+}
+
+int aa_shard_samples(int64_t f0, int64_t f1, int32_t n_fft, int32_t hop, int64_t *s0, int64_t *s1)
+{
+    if (!s0 || !s1 || f0 < 0 || f1 < f0 || n_fft <= 0 || hop <= 0)
+        return fail(AA_ERR_ARG, "aa_shard_samples: bad argument");
+    *s0 = f0 * (int64_t)hop;
+    *s1 = (f1 == f0) ? *s0 : (f1 - 1) * (int64_t)hop + n_fft;
+    return AA_OK;
+}
+
+// --------------------------------------------------------------- streaming front --
+struct aa_stream {
+    aa_stft_plan *plan = nullptr;  // hop == n_fft over gathered frames
+    int n_fft = 0, hop = 0, ring_len = 0;
+    std::vector<float> ring;
+    int64_t write_pos = 0, read_pos = 0, available = 0, abs_read = 0;
+    std::vector<float> gathered;
+};
+
+int aa_stream_create(const aa_stft_config *cfg, int32_t ring_len, aa_stream **out_stream)
+{
+    if (!cfg || !out_stream)
+        return fail(AA_ERR_ARG, "aa_stream_create: NULL argument");
+    *out_stream = nullptr;
+    if (ring_len == 0)
+        ring_len = cfg->n_fft * 4 > 8192 ? cfg->n_fft * 4 : 8192;   // stft.rs:171
+    if (ring_len < cfg->n_fft)
+        return fail(AA_ERR_ARG, "ring_len %d < n_fft %d", ring_len, cfg->n_fft);
+    aa_stream *s = new (std::nothrow) aa_stream();
+    if (!s)
+        return fail(AA_ERR_NOMEM, "aa_stream_create: out of host memory");
+    // The GPU side sees the gathered frames as a gap-free buffer with hop == n_fft.
+    aa_stft_config c = *cfg;
+    c.hop = cfg->n_fft;
+    int rc = aa_stft_plan_create(&c, nullptr, &s->plan);
+    if (cfg->window == AA_WINDOW_CUSTOM)
+        rc = fail(AA_ERR_UNSUPPORTED, "aa_stream: custom windows are not supported");
+    if (rc != AA_OK) {
+        aa_stream_destroy(s);
+        return rc;
+    }
+    s->n_fft = cfg->n_fft;
+    s->hop = cfg->hop;
+    s->ring_len = ring_len;
+    s->ring.assign(ring_len, 0.0f);
+    *out_stream = s;
+    return AA_OK;
+}
+
+int aa_stream_destroy(aa_stream *s)
+{
+    if (!s)
+        return AA_OK;
+    aa_stft_plan_destroy(s->plan);
+    delete s;
+    return AA_OK;
+}
+
+int aa_stream_push(aa_stream *s, const float *slot_host, int32_t slot_len, float *out_host,
+                   int64_t *frame_starts, int64_t max_frames, int64_t *n_emitted)
+{
+    if (!s || (!slot_host && slot_len > 0) || slot_len < 0 || !out_host || !n_emitted ||
+        max_frames < 0)
+        return fail(AA_ERR_ARG, "aa_stream_push: bad argument");
+    *n_emitted = 0;
+    // ingest — stft.rs:247-255 (per-sample modulo write)
+    for (int i = 0; i < slot_len; ++i) {
+        s->ring[s->write_pos] = slot_host[i];
+        s->write_pos = (s->write_pos + 1) % s->ring_len;
+        s->available += 1;
+    }
+    // overflow: drop the oldest samples — stft.rs:262-266
+    if (s->available > s->ring_len) {
+        int64_t excess = s->available - s->ring_len;
+        s->read_pos = (s->read_pos + excess) % s->ring_len;
+        s->abs_read += excess;
+        s->available = s->ring_len;
+    }
+    // frame loop — stft.rs:273, 296-299 (gather only; window + FFT run on the GPU), 436-437
+    int64_t emitted = 0;
+    s->gathered.clear();
+    while (s->available >= s->n_fft && emitted < max_frames) {
+        if (frame_starts)
+            frame_starts[emitted] = s->abs_read;
+        size_t base = s->gathered.size();
+        s->gathered.resize(base + s->n_fft);
+        for (int i = 0; i < s->n_fft; ++i)
+            s->gathered[base + i] = s->ring[(s->read_pos + i) % s->ring_len];
+        s->read_pos = (s->read_pos + s->hop) % s->ring_len;
+        s->abs_read += s->hop;
+        s->available -= s->hop;
+        ++emitted;
+    }
+    if (emitted > 0) {
+        int rc = aa_stft_execute_host(s->plan, s->gathered.data(), (int64_t)s->gathered.size(),
+                                      out_host);
+        if (rc != AA_OK)
+            return rc;
+    }
+    *n_emitted = emitted;
+    return AA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Internal interface between the C-ABI layer (aa_abi.cpp) and the gfx950 kernels
+// (aa_kernels.hip).  Not installed; the public surface is include/aa_stft.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aa {
+
+// Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER).
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3 };
+
+// ---- wave-per-frame 1024-point kernel --------------------------------------
+// Per-lane constant table, row-major [kWave1024Rows][64] floats (see
+// build_wave1024_table in aa_abi.cpp for the row meaning).
+constexpr int kWave1024Rows = 52;
+constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
+constexpr int kWave1024XchDwords = 520;            // per-wave split exchange area
+// LDS dwords needed to stage `span` samples in the padded layout (+8 per 64).
+inline int wave1024_stage_dwords(int span) { return span + 8 * ((span + 63) / 64); }
+inline size_t wave1024_lds_bytes(int frames_per_wg, int hop)
+{
+    int span = (frames_per_wg - 1) * hop + 1024;
+    return sizeof(float) * (size_t)(wave1024_stage_dwords(span) + 4 * kWave1024XchDwords);
+}
+
+hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
+                           int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                           float log_floor, hipStream_t stream);
+
+// ---- generic kernels (any even length) ---------------------------------------
+// Frame t reads x[t*hop + i] * window[i] (window may be null).  Rows of
+// out: kComplex -> 2*(n/2+1) floats, else n/2+1 floats.
+// pow2 == true : LDS Stockham radix-2;  false: direct DFT from a full twiddle table.
+//   tw_m   : W_m^q  (re,im interleaved), q < m/2 (pow2) or q < m (dft), m = n/2
+//   tw_split: W_n^k (re,im interleaved), k <= m/2
+hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float *out,
+                                  const float *window, const float *tw_m, const float *tw_split,
+                                  int n, int64_t frame_begin, int64_t n_frames, int64_t hop,
+                                  float log_floor, hipStream_t stream);
+// Inverse C2R, unnormalised: rows of 2*(n/2+1) floats -> rows of n floats.
+hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, const float *tw_m,
+                                  const float *tw_split, int n, int64_t batch, hipStream_t stream);
+
+}  // namespace aa

@@ -1,0 +1,142 @@
+"""Batched STFT: the frame loop of `STFT::detect_pitches` (src/audio_io/stft.rs:273-318)
+and `OnsetDetector::detect_onsets` (src/analysis/onset.rs:244-272) over a whole buffer.
+
+    plan = Stft(n_fft=2048, hop=512)             # the tuner geometry (stft.rs:169-170)
+    mags = plan(samples)                         # [n_frames, n_fft/2+1], |X| = c.norm()
+
+`samples` may be a numpy float32 array (host path: staged through the plan's device
+workspace) or a CUDA torch.float32 tensor (device path: zero-copy, asynchronous on the
+current torch stream).  Frame t covers samples[t*hop : t*hop + n_fft]; no centring, no
+padding, the trailing partial frame is dropped — exactly the reference's loop.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class Stft:
+    def __init__(self, n_fft, hop=None, window="hann", output="mag", sample_rate=48000,
+                 n_mels=128, n_mfcc=40, fmin=0.0, fmax=0.0, log_floor=0.0):
+        self._lib = _lib.load()
+        hop = n_fft // 4 if hop is None else hop       # hop = N/4 in both reference instances
+        custom = None
+        if isinstance(window, str):
+            wkind = _lib.WINDOW_KINDS[window]
+        else:
+            custom = np.ascontiguousarray(window, dtype=np.float32)
+            if custom.shape != (n_fft,):
+                raise _lib.AaError(_lib.AA_ERR_LEN, "custom window must have n_fft entries")
+            wkind = _lib.AA_WINDOW_CUSTOM
+        cfg = _lib.StftConfig(int(n_fft), int(hop), wkind, _lib.OUTPUT_KINDS[output],
+                              int(sample_rate), int(n_mels), int(n_mfcc), float(fmin), float(fmax),
+                              float(log_floor))
+        self._plan = ctypes.c_void_p()
+        _lib.check(self._lib.aa_stft_plan_create(
+            ctypes.byref(cfg), _lib.f32_ptr(custom) if custom is not None else None,
+            ctypes.byref(self._plan)))
+        self.n_fft, self.hop, self.output = int(n_fft), int(hop), output
+        self.cols = int(self._lib.aa_stft_out_cols(self._plan))
+        self.kernel = self._lib.aa_stft_kernel_name(self._plan).decode()
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._lib.aa_stft_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_frames(self, n_samples):
+        """floor((L - N)/hop) + 1 (stft.rs:273, 436-437); integer-exact."""
+        return int(self._lib.aa_stft_num_frames(self._plan, int(n_samples)))
+
+    def _wrap(self, flat, nf):
+        if self.output == "complex":
+            return flat.reshape(nf, self.cols // 2, 2)
+        return flat.reshape(nf, self.cols)
+
+    def __call__(self, samples, frame_begin=0, frame_end=None, out=None, stream=None):
+        if isinstance(samples, np.ndarray):
+            return self.execute_host(samples)
+        return self.execute_device(samples, frame_begin, frame_end, out, stream)
+
+    def execute_host(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.float32)
+        if x.ndim != 1:
+            raise _lib.AaError(_lib.AA_ERR_ARG, "samples must be one-dimensional (mono)")
+        nf = self.num_frames(x.shape[0])
+        out = np.empty((nf, self.cols), dtype=np.float32)
+        if nf:
+            _lib.check(self._lib.aa_stft_execute_host(self._plan, _lib.f32_ptr(x), x.shape[0],
+                                                      _lib.f32_ptr(out)))
+        return out.view(np.complex64) if self.output == "complex" else out
+
+    def execute_device(self, samples, frame_begin=0, frame_end=None, out=None, stream=None):
+        """samples: CUDA float32 1-D tensor. Returns a CUDA tensor [frames, cols]
+        (complex64 [frames, n_fft/2+1] for output="complex")."""
+        import torch
+
+        if not (samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 1
+                and samples.is_contiguous()):
+            raise _lib.AaError(_lib.AA_ERR_ARG, "samples must be a contiguous 1-D CUDA float32 tensor")
+        total = self.num_frames(samples.shape[0])
+        if frame_end is None:
+            frame_end = total
+        nf = frame_end - frame_begin
+        if out is None:
+            out = torch.empty((max(nf, 0), self.cols), dtype=torch.float32, device=samples.device)
+        st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
+        _lib.check(self._lib.aa_stft_execute_device(self._plan, samples.data_ptr(),
+                                                    samples.shape[0], frame_begin, frame_end,
+                                                    out.data_ptr(), st))
+        if self.output == "complex":
+            return torch.view_as_complex(out.view(-1, self.cols // 2, 2))
+        return out
+
+
+class StftStream:
+    """Streaming front end: the ring-buffer ingest of stft.rs:198-201, 240-266 feeding the
+    GPU frame loop.  `push(slot)` appends one slot (the reference's are 1024 samples,
+    src/audio_io/mod.rs:126-128) and returns (rows, frame_starts) for every completed frame."""
+
+    def __init__(self, n_fft, hop=None, ring_len=0, output="mag", window="hann"):
+        self._lib = _lib.load()
+        hop = n_fft // 4 if hop is None else hop
+        cfg = _lib.StftConfig(int(n_fft), int(hop), _lib.WINDOW_KINDS[window],
+                              _lib.OUTPUT_KINDS[output], 48000, 0, 0, 0.0, 0.0, 0.0)
+        self._s = ctypes.c_void_p()
+        _lib.check(self._lib.aa_stream_create(ctypes.byref(cfg), int(ring_len), ctypes.byref(self._s)))
+        self.n_fft, self.hop, self.output = int(n_fft), int(hop), output
+        self.ring_len = int(ring_len) if ring_len else max(8192, 4 * int(n_fft))
+        nb = n_fft // 2 + 1
+        self.cols = 2 * nb if output == "complex" else nb
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.aa_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, slot):
+        slot = np.ascontiguousarray(slot, dtype=np.float32)
+        cap = slot.shape[0] // self.hop + self.ring_len // self.hop + 2
+        out = np.empty((cap, self.cols), dtype=np.float32)
+        starts = np.empty(cap, dtype=np.int64)
+        n = ctypes.c_int64(0)
+        _lib.check(self._lib.aa_stream_push(
+            self._s, _lib.f32_ptr(slot), slot.shape[0], _lib.f32_ptr(out),
+            starts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), cap, ctypes.byref(n)))
+        rows = out[:n.value]
+        if self.output == "complex":
+            rows = rows.view(np.complex64)
+        return rows, starts[:n.value]

@@ -1,0 +1,183 @@
+/*
+ * aa_stft.h — C ABI of the MI355X-native STFT / spectrogram hot path.
+ *
+ * Drop-in boundary for the one data-parallel path of audio-analyzer-rs:
+ *   window -> real FFT -> |X|      (reference: src/dsp/fft.rs, the frame loops of
+ *   src/audio_io/stft.rs:273-318 and src/analysis/onset.rs:244-272).
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an
+ * int status (AA_OK == 0, negative on error) and never aborts.  The reference
+ * panics instead (`.unwrap()` at src/dsp/fft.rs:69, :99); a Rust wrapper can turn
+ * a non-zero status back into a panic to keep that behaviour.
+ *
+ * Layout conventions
+ *   - complex bins are interleaved (re, im) float pairs == num_complex::Complex<f32>
+ *     (#[repr(C)]), n_fft/2+1 pairs per frame;
+ *   - a batched output is row-major [frame][column], frames in stream order:
+ *     frame t covers samples [t*hop, t*hop + n_fft)  (stft.rs:273, 296-299, 436-437);
+ *   - "device" pointers are HIP device pointers on the plan's device; "host"
+ *     pointers are ordinary host memory (staged through the plan's workspace);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Threading: a plan is not thread-safe; distinct plans are independent
+ * (the reference builds one FftProcessor per worker thread: stft.rs:176-180,
+ * onset.rs:138-141).  A plan binds to the HIP device current at creation.
+ *
+ * The library has NO CPU fallback: if no HIP device is usable every compute
+ * entry point returns AA_ERR_HIP.
+ */
+#ifndef AA_STFT_H
+#define AA_STFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+    AA_OK = 0,
+    AA_ERR_ARG = -1,         /* NULL pointer / bad enum / bad range                 */
+    AA_ERR_LEN = -2,         /* length the plan cannot transform (reference: panic
+                                from realfft's Result, src/dsp/fft.rs:69)           */
+    AA_ERR_HIP = -3,         /* HIP runtime error or no device                      */
+    AA_ERR_NOMEM = -4,
+    AA_ERR_UNSUPPORTED = -5, /* valid request this build does not implement         */
+    AA_ERR_NCCL = -6         /* reserved for collective helpers                     */
+};
+
+/* Last error text of the calling thread ("" if none). Never NULL. */
+const char *aa_last_error(void);
+int aa_abi_version(void);
+/* Number of visible HIP devices (0 and AA_ERR_HIP if the runtime is unusable). */
+int aa_device_count(int *count);
+
+/* ---- window ------------------------------------------------------------- */
+enum {
+    AA_WINDOW_HANN_PERIODIC = 0, /* STFT::hann_window, stft.rs:641-648 / onset.rs:549-556 */
+    AA_WINDOW_RECT = 1,          /* all ones (FftProcessor used bare)                       */
+    AA_WINDOW_CUSTOM = 2         /* caller-supplied n_fft floats                            */
+};
+
+/* Periodic Hann exactly as the reference forms it, every step in f32:
+ *   x = i as f32 / n as f32;  w = 0.5 - 0.5 * cos(2.0 * PI_f32 * x)
+ * Replaces STFT::hann_window(n) (src/audio_io/stft.rs:641-648) and
+ * OnsetDetector::hann_window(n) (src/analysis/onset.rs:549-556).  Host-side, tiny. */
+int aa_hann_window(int n, float *out_host);
+
+/* ---- FftProcessor mirror (src/dsp/fft.rs:6-42) --------------------------- */
+typedef struct aa_fft_plan aa_fft_plan;
+
+/* FftProcessor::new(len) — src/dsp/fft.rs:14-29.  len must be even and >= 4;
+ * powers of two run the LDS radix-2 kernels, other even lengths a direct DFT
+ * kernel (len <= 8192). */
+int aa_fft_create(int len, aa_fft_plan **out_plan);
+int aa_fft_destroy(aa_fft_plan *plan);
+int aa_fft_len(const aa_fft_plan *plan);
+
+/* FftProcessor::process_forward(&mut [f32]) -> &[Complex<f32>] — fft.rs:33-35, 66-71.
+ * Unnormalised forward real DFT of ONE frame: in[len] -> out[2*(len/2+1)].
+ * Unlike the reference the input is const (not used as scratch) and the output
+ * buffer is caller-owned (the reference returns a borrow of plan-owned storage). */
+int aa_fft_forward(aa_fft_plan *plan, const float *in_host, float *out_host);
+
+/* FftProcessor::process_inverse(&mut [Complex<f32>]) -> &[f32] — fft.rs:39-41, 96-101.
+ * Unnormalised inverse (inverse(forward(x)) == len * x): spec[2*(len/2+1)] -> out[len].
+ * Imaginary parts of bin 0 and bin len/2 are ignored (status stays AA_OK). */
+int aa_fft_inverse(aa_fft_plan *plan, const float *spec_host, float *out_host);
+
+/* Batched forms on device memory: `batch` independent frames, contiguous rows
+ * (row stride len floats in / 2*(len/2+1) floats out for forward, the reverse for
+ * inverse).  These are what a GPU caller should use instead of per-frame calls. */
+int aa_fft_forward_batch_device(aa_fft_plan *plan, const float *in_dev, float *out_dev,
+                                int64_t batch, void *stream);
+int aa_fft_inverse_batch_device(aa_fft_plan *plan, const float *spec_dev, float *out_dev,
+                                int64_t batch, void *stream);
+
+/* ---- batched STFT (the frame loops of stft.rs:273-318 / onset.rs:244-272) -- */
+enum {
+    AA_OUT_COMPLEX = 0,  /* Complex<f32> bins, 2*(n_fft/2+1) floats per frame (fft.rs:33)  */
+    AA_OUT_MAG = 1,      /* |X| = c.norm(), n_fft/2+1 floats (stft.rs:314-318, onset.rs:271) */
+    AA_OUT_POWER = 2,    /* |X|^2                         — build-defined, not in reference  */
+    AA_OUT_LOGPOWER = 3, /* 10*log10(max(|X|^2, floor))   — build-defined, not in reference  */
+    AA_OUT_LOGMEL = 4,   /* 10*log10(max(mel @ |X|^2, floor)), n_mels floats — build-defined */
+    AA_OUT_MFCC = 5      /* DCT-II(ortho) of log-mel, n_mfcc floats      — build-defined     */
+};
+
+typedef struct aa_stft_config {
+    int32_t n_fft;       /* window / transform length: 2048 tuner (stft.rs:170), 256 onset
+                            (onset.rs:122); BASELINE bench: 1024                           */
+    int32_t hop;         /* hop size: n_fft/4 in the reference (stft.rs:169, onset.rs:123) */
+    int32_t window;      /* AA_WINDOW_*                                                    */
+    int32_t output;      /* AA_OUT_*                                                       */
+    int32_t sample_rate; /* Hz; only used by mel outputs (reference streams run at the
+                            device rate, e.g. 48000)                                       */
+    int32_t n_mels;      /* AA_OUT_LOGMEL / AA_OUT_MFCC                                    */
+    int32_t n_mfcc;      /* AA_OUT_MFCC                                                    */
+    float fmin;          /* mel lower edge (Hz)                                            */
+    float fmax;          /* mel upper edge (Hz); <= 0 means sample_rate/2                  */
+    float log_floor;     /* clamp before log10; <= 0 means 1e-10                           */
+} aa_stft_config;
+
+typedef struct aa_stft_plan aa_stft_plan;
+
+/* custom_window_host: n_fft floats when cfg->window == AA_WINDOW_CUSTOM, else NULL. */
+int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_host,
+                        aa_stft_plan **out_plan);
+int aa_stft_plan_destroy(aa_stft_plan *plan);
+
+/* floor((n_samples - n_fft)/hop) + 1, or 0 when n_samples < n_fft: the count the
+ * `while available_samples >= window_size` loop emits for a gap-free stream
+ * (stft.rs:273, 436-437).  Pure integer; bit-exact by construction. */
+int64_t aa_stft_num_frames(const aa_stft_plan *plan, int64_t n_samples);
+/* floats per output row for the plan's output kind. */
+int32_t aa_stft_out_cols(const aa_stft_plan *plan);
+/* Name of the kernel path the plan selected ("wave1024", "lds_radix2", "dft"). */
+const char *aa_stft_kernel_name(const aa_stft_plan *plan);
+
+/* Frames [frame_begin, frame_end) of the buffer `samples_dev[0 .. n_samples)`,
+ * rows written from out_dev[0].  frame indices are relative to samples_dev[0]:
+ * frame t reads samples_dev[t*hop .. t*hop+n_fft).  Asynchronous on `stream`. */
+int aa_stft_execute_device(aa_stft_plan *plan, const float *samples_dev, int64_t n_samples,
+                           int64_t frame_begin, int64_t frame_end, float *out_dev,
+                           void *stream);
+/* All frames of a host buffer; synchronous (H2D, kernels, D2H through the
+ * plan's workspace).  out_host holds aa_stft_num_frames * aa_stft_out_cols floats. */
+int aa_stft_execute_host(aa_stft_plan *plan, const float *samples_host, int64_t n_samples,
+                         float *out_host);
+
+/* ---- frame-range sharding (one rank per GPU) --------------- */
+/* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs
+ * samples [f0*hop, (f1-1)*hop + n_fft) — a halo of n_fft-hop samples shared with
+ * the next rank.  Frame indices stay global, so indexing is bit-exact whatever the
+ * world size.  Empty ranges give f0 == f1 and s0 == s1. */
+int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *f0,
+                    int64_t *f1);
+int aa_shard_samples(int64_t f0, int64_t f1, int32_t n_fft, int32_t hop, int64_t *s0,
+                     int64_t *s1);
+
+/* ---- streaming front end (ring-buffer ingest of stft.rs:198-201, 240-266) -- */
+typedef struct aa_stream aa_stream;
+
+/* ring_len: 8192.max(4*n_fft) for the tuner (stft.rs:171), 4096 for onsets
+ * (onset.rs:124); pass 0 for max(8192, 4*n_fft).  The stream owns a plan-shaped
+ * GPU pipeline; frames are computed in batches when aa_stream_push is called. */
+int aa_stream_create(const aa_stft_config *cfg, int32_t ring_len, aa_stream **out_stream);
+int aa_stream_destroy(aa_stream *stream);
+/* Append one slot of samples (the reference's slots are 1024 f32, mod.rs:126-128),
+ * apply the overflow rule (oldest samples dropped, stft.rs:262-266), then emit every
+ * complete frame: rows are written to out_host (capacity max_frames rows) and the
+ * absolute stream index of each frame's first sample to frame_starts (may be NULL).
+ * *n_emitted receives the number of rows written. */
+int aa_stream_push(aa_stream *stream, const float *slot_host, int32_t slot_len,
+                   float *out_host, int64_t *frame_starts, int64_t max_frames,
+                   int64_t *n_emitted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AA_STFT_H */

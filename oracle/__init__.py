@@ -1,0 +1,22 @@
+"""CPU oracle for the STFT hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package, and only as the checker / the timed CPU leg.  The
+product package (``audio_analyzer_rs_amd``) never imports it.
+
+PARITY UNPINNED by the reference: it holds no test, fixture or golden vector for
+src/dsp/fft.rs, src/audio_io/stft.rs or src/analysis/onset.rs, and it is Rust,
+which cannot be built in this image.  The oracle is pinned against a float64
+``numpy.fft.rfft`` truth instead (``oracle.truth``).
+"""
+from .capi import (  # noqa: F401
+    Oracle,
+    build_oracle,
+    hann_window,
+    num_frames,
+    rfft_forward,
+    rfft_inverse,
+    stft,
+    stream_frame_starts,
+)
+from . import truth  # noqa: F401

@@ -1,0 +1,176 @@
+"""ctypes bindings for oracle/libstft_oracle.so (the C restatement).
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libstft_oracle.so")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build_oracle(force=False):
+    """Compile oracle/stft_oracle.c with the committed Makefile (gcc)."""
+    src = os.path.join(_HERE, "stft_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_f32p)
+
+
+class Oracle:
+    _inst = None
+
+    def __init__(self):
+        if not os.path.exists(_SO):
+            build_oracle()
+        lib = ctypes.CDLL(_SO)
+        lib.aao_hann_window.argtypes = [ctypes.c_int, _f32p]
+        lib.aao_hann_window.restype = None
+        lib.aao_num_frames.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+        lib.aao_num_frames.restype = ctypes.c_int64
+        lib.aao_plan_create.argtypes = [ctypes.c_int]
+        lib.aao_plan_create.restype = ctypes.c_void_p
+        lib.aao_plan_destroy.argtypes = [ctypes.c_void_p]
+        lib.aao_plan_destroy.restype = None
+        lib.aao_rfft_forward.argtypes = [ctypes.c_void_p, _f32p, _f32p]
+        lib.aao_rfft_forward.restype = ctypes.c_int
+        lib.aao_rfft_inverse.argtypes = [ctypes.c_void_p, _f32p, _f32p]
+        lib.aao_rfft_inverse.restype = ctypes.c_int
+        lib.aao_magnitude.argtypes = [ctypes.c_int, _f32p, _f32p]
+        lib.aao_magnitude.restype = None
+        lib.aao_stft_range.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                       _f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _f32p]
+        lib.aao_stft_range.restype = ctypes.c_int64
+        lib.aao_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.aao_stream_create.restype = ctypes.c_void_p
+        lib.aao_stream_destroy.argtypes = [ctypes.c_void_p]
+        lib.aao_stream_destroy.restype = None
+        lib.aao_stream_push.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, _i64p, _f32p,
+                                        ctypes.c_int64]
+        lib.aao_stream_push.restype = ctypes.c_int64
+        lib.aao_lcg_next.argtypes = [ctypes.c_uint32]
+        lib.aao_lcg_next.restype = ctypes.c_uint32
+        self.lib = lib
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+
+def hann_window(n):
+    """Periodic f32 Hann (reference: src/audio_io/stft.rs:641-648)."""
+    w = np.empty(n, dtype=np.float32)
+    Oracle.get().lib.aao_hann_window(n, _ptr(w))
+    return w
+
+
+def num_frames(n_samples, n_fft, hop):
+    return int(Oracle.get().lib.aao_num_frames(n_samples, n_fft, hop))
+
+
+def rfft_forward(x):
+    """Unnormalised R2C of one f32 frame -> complex64[n/2+1] (src/dsp/fft.rs:33-35)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    lib = Oracle.get().lib
+    p = lib.aao_plan_create(n)
+    if not p:
+        raise ValueError(f"oracle: unsupported FFT length {n}")
+    out = np.empty(2 * (n // 2 + 1), dtype=np.float32)
+    try:
+        rc = lib.aao_rfft_forward(p, _ptr(x), _ptr(out))
+    finally:
+        lib.aao_plan_destroy(p)
+    if rc != 0:
+        raise RuntimeError(f"oracle rfft_forward rc={rc}")
+    return out.view(np.complex64)
+
+
+def rfft_inverse(spec, n):
+    """Unnormalised C2R (src/dsp/fft.rs:39-41): returns n*x for spec = rfft(x)."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex64)
+    assert spec.shape[0] == n // 2 + 1
+    lib = Oracle.get().lib
+    p = lib.aao_plan_create(n)
+    if not p:
+        raise ValueError(f"oracle: unsupported FFT length {n}")
+    out = np.empty(n, dtype=np.float32)
+    try:
+        rc = lib.aao_rfft_inverse(p, _ptr(spec.view(np.float32)), _ptr(out))
+    finally:
+        lib.aao_plan_destroy(p)
+    if rc < 0:
+        raise RuntimeError(f"oracle rfft_inverse rc={rc}")
+    return out
+
+
+def stft(x, n_fft, hop, kind="mag", window=None, f0=0, f1=None):
+    """Frame loop of stft.rs:273-318 over a gap-free buffer.
+
+    kind: "complex" -> complex64[frames, n/2+1]; "mag" -> float32[frames, n/2+1].
+    """
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    nf = num_frames(x.shape[0], n_fft, hop)
+    if f1 is None:
+        f1 = nf
+    if window is None:
+        window = hann_window(n_fft)
+    window = np.ascontiguousarray(window, dtype=np.float32)
+    nb = n_fft // 2 + 1
+    k = 0 if kind == "complex" else 1
+    out = np.empty((f1 - f0, nb * (2 if k == 0 else 1)), dtype=np.float32)
+    if f1 - f0 == 0:
+        return out.view(np.complex64) if k == 0 else out
+    rc = Oracle.get().lib.aao_stft_range(_ptr(x), x.shape[0], n_fft, hop, _ptr(window), k,
+                                         f0, f1, _ptr(out))
+    if rc < 0:
+        raise RuntimeError(f"oracle stft rc={rc}")
+    return out.view(np.complex64) if k == 0 else out
+
+
+def stream_frame_starts(slot_lens, n_fft, hop, ring_len, slot_data=None, return_frames=False):
+    """Run the ring-buffer ingest (stft.rs:240-266, 273, 436-437) over a slot sequence.
+
+    slot_lens: number of samples pushed before each drain (the reference pushes
+    every queued slot and then drains; pass one combined length per drain).
+    Returns the absolute first-sample index of every emitted frame (and the frames).
+    """
+    lib = Oracle.get().lib
+    s = lib.aao_stream_create(n_fft, hop, ring_len)
+    if not s:
+        raise ValueError("bad stream params")
+    starts, frames = [], []
+    pos = 0
+    try:
+        for L in slot_lens:
+            if slot_data is None:
+                slot = np.zeros(L, dtype=np.float32)
+            else:
+                slot = np.ascontiguousarray(slot_data[pos:pos + L], dtype=np.float32)
+            pos += L
+            cap = L // hop + ring_len // hop + 2
+            st = np.empty(cap, dtype=np.int64)
+            fr = np.empty((cap, n_fft), dtype=np.float32) if return_frames else None
+            n = lib.aao_stream_push(s, _ptr(slot), L, st.ctypes.data_as(_i64p),
+                                    _ptr(fr) if fr is not None else None, cap)
+            starts.extend(st[:n].tolist())
+            if return_frames:
+                frames.append(fr[:n].copy())
+    finally:
+        lib.aao_stream_destroy(s)
+    if return_frames:
+        return np.array(starts, dtype=np.int64), (np.concatenate(frames) if frames else
+                                                  np.empty((0, n_fft), np.float32))
+    return np.array(starts, dtype=np.int64)

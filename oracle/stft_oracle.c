@@ -1,0 +1,416 @@
+/*
+ * stft_oracle.c — CPU restatement of audio-analyzer-rs's STFT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker / the timed CPU leg.
+ *
+ * PARITY UNPINNED: the reference holds no test, fixture or golden vector for
+ * this path (no #[test] in src/dsp/fft.rs, src/audio_io/stft.rs or
+ * src/analysis/onset.rs) and it is Rust, which cannot be built in this image
+ * (no cargo/rustc).  The butterflies live in un-vendored crates (realfft 3.5.0,
+ * rustfft 6.4.1, num-complex 0.4.6 — Cargo.lock).  This file restates the
+ * published algorithm those crates implement and is pinned instead against a
+ * float64 numpy.fft.rfft truth (oracle/truth.py, tests/test_oracle.py).
+ *
+ * Each function cites the reference lines it follows (paths relative to the
+ * reference repository root).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define AAO_OK 0
+#define AAO_ERR_LEN -1
+#define AAO_ERR_ARG -2
+
+/* ---------------------------------------------------------------- window -- */
+
+/* Periodic Hann, every operation in f32.
+ * Follows src/audio_io/stft.rs:641-648 (duplicate: src/analysis/onset.rs:549-556):
+ *   x = (i as f32) / (n as f32);  0.5 - 0.5 * (2.0 * PI_f32 * x).cos()           */
+void aao_hann_window(int n, float *w)
+{
+    const float pi_f32 = 3.14159265358979323846f;
+    for (int i = 0; i < n; ++i) {
+        float x = (float)i / (float)n;
+        float arg = 2.0f * pi_f32 * x;
+        w[i] = 0.5f - 0.5f * cosf(arg);
+    }
+}
+
+/* --------------------------------------------------------------- framing -- */
+
+/* Number of frames the `while available_samples >= window_size` loop emits
+ * for a gap-free stream of n_samples (src/audio_io/stft.rs:273, 436-437;
+ * src/analysis/onset.rs:244, 541-542): floor((L - N) / hop) + 1, 0 if L < N. */
+int64_t aao_num_frames(int64_t n_samples, int n_fft, int hop)
+{
+    if (n_fft <= 0 || hop <= 0 || n_samples < n_fft)
+        return 0;
+    return (n_samples - n_fft) / hop + 1;
+}
+
+/* ------------------------------------------------------------------ plan -- */
+
+typedef struct {
+    int n;          /* real length (even) */
+    int m;          /* n / 2 : complex FFT length */
+    int log2m;      /* valid when pow2 */
+    int pow2;
+    float *tw_re;   /* W_m^k, k < m/2 (pow2 path) or m*m table index k (generic) */
+    float *tw_im;
+    float *sp_re;   /* split twiddles W_n^k, k <= m/2 */
+    float *sp_im;
+    uint32_t *rev;  /* bit reversal (pow2 path) */
+    float *buf_re, *buf_im; /* scratch m */
+} aao_plan;
+
+static int ilog2_exact(int v)
+{
+    int l = 0;
+    while ((1 << l) < v)
+        ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+/* Mirrors FftProcessor::new (src/dsp/fft.rs:14-29): plan + owned scratch.
+ * Twiddles are evaluated in f64 and stored as f32, the way rustfft's
+ * twiddle helper does [recollection — crate source not in this image].       */
+aao_plan *aao_plan_create(int n)
+{
+    if (n < 2 || (n & 1))
+        return NULL;
+    aao_plan *p = (aao_plan *)calloc(1, sizeof(aao_plan));
+    p->n = n;
+    p->m = n / 2;
+    p->log2m = ilog2_exact(p->m);
+    p->pow2 = p->log2m >= 0;
+    int m = p->m;
+    int ntw = p->pow2 ? (m / 2 > 0 ? m / 2 : 1) : m;
+    p->tw_re = (float *)malloc(sizeof(float) * ntw);
+    p->tw_im = (float *)malloc(sizeof(float) * ntw);
+    for (int k = 0; k < ntw; ++k) {
+        double a = -2.0 * M_PI * (double)k / (double)m;
+        p->tw_re[k] = (float)cos(a);
+        p->tw_im[k] = (float)sin(a);
+    }
+    p->sp_re = (float *)malloc(sizeof(float) * (m / 2 + 1));
+    p->sp_im = (float *)malloc(sizeof(float) * (m / 2 + 1));
+    for (int k = 0; k <= m / 2; ++k) {
+        double a = -2.0 * M_PI * (double)k / (double)n;
+        p->sp_re[k] = (float)cos(a);
+        p->sp_im[k] = (float)sin(a);
+    }
+    p->buf_re = (float *)malloc(sizeof(float) * m);
+    p->buf_im = (float *)malloc(sizeof(float) * m);
+    if (p->pow2) {
+        p->rev = (uint32_t *)malloc(sizeof(uint32_t) * m);
+        for (int i = 0; i < m; ++i) {
+            uint32_t r = 0;
+            for (int b = 0; b < p->log2m; ++b)
+                if (i & (1 << b))
+                    r |= 1u << (p->log2m - 1 - b);
+            p->rev[i] = r;
+        }
+    }
+    return p;
+}
+
+void aao_plan_destroy(aao_plan *p)
+{
+    if (!p)
+        return;
+    free(p->tw_re); free(p->tw_im); free(p->sp_re); free(p->sp_im);
+    free(p->rev); free(p->buf_re); free(p->buf_im);
+    free(p);
+}
+
+int aao_plan_len(const aao_plan *p) { return p ? p->n : 0; }
+
+/* ----------------------------------------------------------- complex FFT -- */
+
+/* In-place radix-2 decimation-in-time on split re/im arrays that are already
+ * in bit-reversed order.  sign = -1 forward, +1 inverse (conjugate twiddles). */
+static void cfft_pow2(const aao_plan *p, float *re, float *im, int sign)
+{
+    const int m = p->m;
+    for (int half = 1; half < m; half <<= 1) {
+        const int step = m / (2 * half); /* twiddle stride */
+        for (int base = 0; base < m; base += 2 * half) {
+            float *ar = re + base, *ai = im + base;
+            float *br = ar + half, *bi = ai + half;
+            for (int j = 0; j < half; ++j) {
+                float wr = p->tw_re[j * step];
+                float wi = (sign < 0) ? p->tw_im[j * step] : -p->tw_im[j * step];
+                float tr = br[j] * wr - bi[j] * wi;
+                float ti = br[j] * wi + bi[j] * wr;
+                br[j] = ar[j] - tr;
+                bi[j] = ai[j] - ti;
+                ar[j] = ar[j] + tr;
+                ai[j] = ai[j] + ti;
+            }
+        }
+    }
+}
+
+/* O(m^2) DFT for non-power-of-two half lengths (correctness only; the
+ * reference only ever instantiates 2048 and 256 — stft.rs:169-170,
+ * onset.rs:122-123).  Accumulates in f64 so it also serves as a cross-check. */
+static void cdft_generic(const aao_plan *p, const float *xr, const float *xi,
+                         float *yr, float *yi, int sign)
+{
+    const int m = p->m;
+    for (int k = 0; k < m; ++k) {
+        double sr = 0.0, si = 0.0;
+        for (int j = 0; j < m; ++j) {
+            int idx = (int)(((int64_t)j * k) % m);
+            double wr = p->tw_re[idx], wi = (sign < 0) ? p->tw_im[idx] : -p->tw_im[idx];
+            sr += (double)xr[j] * wr - (double)xi[j] * wi;
+            si += (double)xr[j] * wi + (double)xi[j] * wr;
+        }
+        yr[k] = (float)sr;
+        yi[k] = (float)si;
+    }
+}
+
+/* ------------------------------------------------------------ real  FFT -- */
+
+/* Unnormalised forward real DFT, n/2+1 interleaved (re,im) bins.
+ * Contract: FftProcessor::process_forward (src/dsp/fft.rs:33-35) →
+ * FftForward::process (:66-71) → realfft RealToComplex::process_with_scratch.
+ * Algorithm (realfft's even-length path, restated): view x[n] as m = n/2
+ * complex samples z[j] = x[2j] + i x[2j+1], run an m-point complex FFT, then
+ *   X[k] = (Z[k] + conj(Z[m-k]))/2 - i W_n^k (Z[k] - conj(Z[m-k]))/2 ,
+ * X[0] = Re Z0 + Im Z0, X[m] = Re Z0 - Im Z0 (both with zero imaginary part). */
+int aao_rfft_forward(aao_plan *p, const float *in, float *out)
+{
+    if (!p || !in || !out)
+        return AAO_ERR_ARG;
+    const int m = p->m;
+    float *zr = p->buf_re, *zi = p->buf_im;
+    if (p->pow2) {
+        for (int j = 0; j < m; ++j) {
+            uint32_t r = p->rev[j];
+            zr[r] = in[2 * j];
+            zi[r] = in[2 * j + 1];
+        }
+        cfft_pow2(p, zr, zi, -1);
+    } else {
+        float *tr = (float *)malloc(sizeof(float) * 2 * m), *ti = tr + m;
+        for (int j = 0; j < m; ++j) {
+            tr[j] = in[2 * j];
+            ti[j] = in[2 * j + 1];
+        }
+        cdft_generic(p, tr, ti, zr, zi, -1);
+        free(tr);
+    }
+    out[0] = zr[0] + zi[0];
+    out[1] = 0.0f;
+    out[2 * m] = zr[0] - zi[0];
+    out[2 * m + 1] = 0.0f;
+    for (int k = 1; k <= m / 2; ++k) {
+        int kk = m - k;
+        if (kk < k)
+            break;
+        float ar = zr[k], ai = zi[k];
+        float br = zr[kk], bi = -zi[kk]; /* conj(Z[m-k]) */
+        float er = 0.5f * (ar + br), ei = 0.5f * (ai + bi);
+        float orr = 0.5f * (ar - br), oi = 0.5f * (ai - bi);
+        float wr = p->sp_re[k], wi = p->sp_im[k];
+        /* t = -i * W * O */
+        float pr = wr * orr - wi * oi, pi = wr * oi + wi * orr; /* W*O */
+        float tr = pi, ti = -pr;
+        out[2 * k] = er + tr;
+        out[2 * k + 1] = ei + ti;
+        /* X[m-k] = conj(E - t) */
+        out[2 * kk] = er - tr;
+        out[2 * kk + 1] = -(ei - ti);
+    }
+    return AAO_OK;
+}
+
+/* Unnormalised inverse (ifft(fft(x)) = n·x): FftProcessor::process_inverse
+ * (src/dsp/fft.rs:39-41, 96-101).  Never called in the reference; kept for
+ * boundary completeness.  Imaginary parts of X[0] and X[n/2] are ignored
+ * (realfft reports an error for non-zero values there [recollection]; the
+ * status return of 1 flags that case without aborting).                        */
+int aao_rfft_inverse(aao_plan *p, const float *spec, float *out)
+{
+    if (!p || !spec || !out)
+        return AAO_ERR_ARG;
+    const int m = p->m;
+    float *zr = p->buf_re, *zi = p->buf_im;
+    int warn = (spec[1] != 0.0f || spec[2 * m + 1] != 0.0f) ? 1 : 0;
+    /* Z[k] = (X[k] + conj(X[m-k])) + i conj(W_n^k) (X[k] - conj(X[m-k])) */
+    float *tr = (float *)malloc(sizeof(float) * 2 * m), *ti = tr + m;
+    for (int k = 0; k < m; ++k) {
+        int kk = m - k;
+        float ar = spec[2 * k], ai = (k == 0) ? 0.0f : spec[2 * k + 1];
+        float br = spec[2 * kk], bi = (kk == m) ? 0.0f : -spec[2 * kk + 1];
+        float er = ar + br, ei = ai + bi;
+        float orr = ar - br, oi = ai - bi;
+        double a = 2.0 * M_PI * (double)k / (double)p->n;
+        float wr = (float)cos(a), wi = (float)sin(a);
+        float pr = wr * orr - wi * oi, pi = wr * oi + wi * orr;
+        /* i * (pr + i pi) = -pi + i pr */
+        tr[k] = er - pi;
+        ti[k] = ei + pr;
+    }
+    if (p->pow2) {
+        for (int j = 0; j < m; ++j) {
+            uint32_t r = p->rev[j];
+            zr[r] = tr[j];
+            zi[r] = ti[j];
+        }
+        cfft_pow2(p, zr, zi, +1);
+    } else {
+        cdft_generic(p, tr, ti, zr, zi, +1);
+    }
+    free(tr);
+    for (int j = 0; j < m; ++j) {
+        out[2 * j] = zr[j];
+        out[2 * j + 1] = zi[j];
+    }
+    return warn;
+}
+
+/* ------------------------------------------------------------- magnitude -- */
+
+/* mag[k] = c.norm() (src/audio_io/stft.rs:314-318, src/analysis/onset.rs:271-272);
+ * num-complex's norm() is re.hypot(im) [recollection]; no scaling by N or by
+ * the window gain.                                                             */
+void aao_magnitude(int nbins, const float *spec, float *mag)
+{
+    for (int k = 0; k < nbins; ++k)
+        mag[k] = hypotf(spec[2 * k], spec[2 * k + 1]);
+}
+
+/* ------------------------------------------------------------ batch STFT -- */
+
+/* The frame loop of STFT::detect_pitches (src/audio_io/stft.rs:273-318) and
+ * OnsetDetector::detect_onsets (src/analysis/onset.rs:244-272) for a gap-free
+ * buffer: frame t = x[t*hop .. t*hop + n), multiplied by the window with a
+ * single f32 rounding (stft.rs:296-299), forward FFT (:306), then either the
+ * complex bins or norm() magnitudes.  Frames [f0, f1) only, rows written from
+ * out[0]; returns the number of frames written or a negative error.
+ * kind: 0 = complex (re,im interleaved, n/2+1 pairs per row), 1 = magnitude.   */
+int64_t aao_stft_range(const float *x, int64_t n_samples, int n_fft, int hop,
+                       const float *window, int kind, int64_t f0, int64_t f1,
+                       float *out)
+{
+    if (!x || !out || !window || hop <= 0)
+        return AAO_ERR_ARG;
+    aao_plan *p = aao_plan_create(n_fft);
+    if (!p)
+        return AAO_ERR_LEN;
+    int64_t nf = aao_num_frames(n_samples, n_fft, hop);
+    if (f0 < 0 || f1 > nf || f0 > f1) {
+        aao_plan_destroy(p);
+        return AAO_ERR_ARG;
+    }
+    const int nb = n_fft / 2 + 1;
+    float *tw = (float *)malloc(sizeof(float) * n_fft);
+    float *spec = (float *)malloc(sizeof(float) * 2 * nb);
+    for (int64_t t = f0; t < f1; ++t) {
+        const float *src = x + t * (int64_t)hop;
+        for (int i = 0; i < n_fft; ++i)
+            tw[i] = src[i] * window[i];
+        if (kind == 0) {
+            aao_rfft_forward(p, tw, out + (t - f0) * (int64_t)(2 * nb));
+        } else {
+            aao_rfft_forward(p, tw, spec);
+            aao_magnitude(nb, spec, out + (t - f0) * (int64_t)nb);
+        }
+    }
+    free(tw);
+    free(spec);
+    aao_plan_destroy(p);
+    return f1 - f0;
+}
+
+/* ------------------------------------------------- streaming ring buffer -- */
+
+/* Restatement of the ingest + ring-buffer + hop-advance logic
+ * (src/audio_io/stft.rs:198-201, 240-266, 273, 296-299, 436-437;
+ * src/analysis/onset.rs:143-146, 216-237, 244, 254-257, 541-542):
+ * slots are appended sample by sample with a modulo write index; if more than
+ * ring_len samples are pending the read index jumps forward (oldest samples
+ * dropped); frames are emitted while available >= n_fft.  What is recorded
+ * for each emitted frame is the ABSOLUTE index of its first sample in the
+ * input stream, which is what "bit-exact frame indexing" is tested on.        */
+typedef struct {
+    int n_fft, hop, ring_len;
+    float *ring;
+    int64_t write_pos, read_pos, available;
+    int64_t abs_read; /* absolute stream index of ring[read_pos] */
+} aao_stream;
+
+aao_stream *aao_stream_create(int n_fft, int hop, int ring_len)
+{
+    if (n_fft <= 0 || hop <= 0 || ring_len < n_fft)
+        return NULL;
+    aao_stream *s = (aao_stream *)calloc(1, sizeof(aao_stream));
+    s->n_fft = n_fft;
+    s->hop = hop;
+    s->ring_len = ring_len;
+    s->ring = (float *)calloc(ring_len, sizeof(float));
+    return s;
+}
+
+void aao_stream_destroy(aao_stream *s)
+{
+    if (s) {
+        free(s->ring);
+        free(s);
+    }
+}
+
+/* Push one slot (stft.rs:240-266), then drain frames (stft.rs:273-437).
+ * frame_starts receives the absolute first-sample index of each emitted
+ * frame; frames (optional, may be NULL) receives the un-windowed n_fft samples
+ * of each frame.  Returns the number of frames emitted (<= max_frames).       */
+int64_t aao_stream_push(aao_stream *s, const float *slot, int slot_len,
+                        int64_t *frame_starts, float *frames, int64_t max_frames)
+{
+    for (int i = 0; i < slot_len; ++i) {
+        s->ring[s->write_pos] = slot[i];
+        s->write_pos = (s->write_pos + 1) % s->ring_len;
+        s->available += 1;
+    }
+    if (s->available > s->ring_len) {
+        int64_t excess = s->available - s->ring_len;
+        s->read_pos = (s->read_pos + excess) % s->ring_len;
+        s->abs_read += excess;
+        s->available = s->ring_len;
+    }
+    int64_t emitted = 0;
+    while (s->available >= s->n_fft && emitted < max_frames) {
+        if (frame_starts)
+            frame_starts[emitted] = s->abs_read;
+        if (frames)
+            for (int i = 0; i < s->n_fft; ++i)
+                frames[emitted * (int64_t)s->n_fft + i] =
+                    s->ring[(s->read_pos + i) % s->ring_len];
+        s->read_pos = (s->read_pos + s->hop) % s->ring_len;
+        s->abs_read += s->hop;
+        s->available -= s->hop;
+        ++emitted;
+    }
+    return emitted;
+}
+
+/* ------------------------------------------------------ synthetic signals -- */
+
+/* LCG of the reference's metronome noise tick (src/generators/metronome.rs:56-57):
+ *   seed = (seed.wrapping_mul(1103515245).wrapping_add(12345)) & 0x7FFFFFFF
+ * (the u32 wrap is irrelevant under the 31-bit mask).                          */
+uint32_t aao_lcg_next(uint32_t seed)
+{
+    return (uint32_t)(((uint64_t)seed * 1103515245ull + 12345ull) & 0x7FFFFFFFull);
+}

@@ -1,0 +1,314 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(include/aa_stft.h) via the ctypes host mirror; the CPU oracle / float64 truth is only
+the checker.  Tolerances: per frame max_k|out-ref| / max_k|ref| <= 1e-5 against the CPU
+restatement (BASELINE.json north_star), <= 5e-6 against the float64 truth; frame
+indexing exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_GEOMETRIES, GOLDEN_SIGNALS, TOL_VS_ORACLE, TOL_VS_TRUTH
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aa():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import audio_analyzer_rs_amd as aa_mod
+
+    aa_mod.load_library()
+    return aa_mod
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    return torch
+
+
+def nerr(out, ref):
+    from oracle import truth
+
+    return truth.max_normalised_error(np.asarray(out), np.asarray(ref))
+
+
+# ------------------------------------------------------------------ golden vectors --
+@pytest.mark.parametrize("n,hop", GOLDEN_GEOMETRIES)
+@pytest.mark.parametrize("name", GOLDEN_SIGNALS)
+def test_golden_vectors_through_abi(aa, golden, n, hop, name):
+    x = golden[f"n{n}_{name}_x"]
+    T = golden[f"n{n}_{name}_X"]
+    C = aa.Stft(n, hop, output="complex")(x)
+    M = aa.Stft(n, hop, output="mag")(x)
+    assert C.shape == T.shape and M.shape == T.shape
+    if name == "silence":
+        assert not C.any() and not M.any()
+        return
+    assert nerr(C, T).max() < TOL_VS_TRUTH
+    assert nerr(M, np.abs(T)).max() < TOL_VS_TRUTH
+
+
+def test_kernel_selection(aa):
+    assert aa.Stft(1024, 256).kernel == "wave1024"
+    assert aa.Stft(1024, 100).kernel == "lds_radix2"     # hop not a multiple of 64
+    assert aa.Stft(2048, 512).kernel == "lds_radix2"
+    assert aa.Stft(1000, 250).kernel == "dft"
+
+
+# ------------------------------------------------------- wave1024 vs the CPU oracle --
+@pytest.mark.parametrize("n_frames", [1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 100, 1000, 4097])
+@pytest.mark.parametrize("output", ["mag", "complex"])
+def test_wave1024_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
+    n, hop = 1024, 256
+    rng = np.random.default_rng(n_frames)
+    L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))      # ragged tail is dropped
+    x = (0.5 * rng.standard_normal(L)).astype(np.float32)
+    plan = aa.Stft(n, hop, output=output)
+    assert plan.kernel == "wave1024"
+    assert plan.num_frames(L) == n_frames == oracle_mod.num_frames(L, n, hop)
+    got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle_mod.stft(x, n, hop, kind=output)
+    w = oracle_mod.hann_window(n)
+    tru = oracle_mod.truth.stft_complex(x, n, hop, w)
+    tru = tru if output == "complex" else np.abs(tru)
+    assert got.shape == ref.shape
+    assert nerr(got, ref.astype(tru.dtype)).max() < TOL_VS_ORACLE
+    assert nerr(got, tru).max() < TOL_VS_TRUTH
+
+
+@pytest.mark.parametrize("hop", [64, 128, 256, 512, 1024, 1088])
+def test_wave1024_hops(aa, oracle_mod, torch_mod, hop):
+    n = 1024
+    rng = np.random.default_rng(hop)
+    x = rng.uniform(-1, 1, n + 70 * hop + 5).astype(np.float32)
+    plan = aa.Stft(n, hop, output="mag")
+    assert plan.kernel == "wave1024"
+    got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle_mod.stft(x, n, hop, kind="mag")
+    assert got.shape == ref.shape
+    assert nerr(got, ref.astype(np.float64)).max() < TOL_VS_ORACLE
+
+
+def test_wave1024_power_and_logpower(aa, oracle_mod, torch_mod):
+    n, hop = 1024, 256
+    x = aa.signals.synth_corpus(12345, n + 99 * hop)
+    w = oracle_mod.hann_window(n)
+    P = np.abs(oracle_mod.truth.stft_complex(x, n, hop, w)) ** 2
+    xd = torch_mod.from_numpy(x).cuda()
+    got_p = aa.Stft(n, hop, output="power")(xd).cpu().numpy()
+    assert nerr(got_p, P).max() < 2 * TOL_VS_TRUTH
+    got_l = aa.Stft(n, hop, output="logpower")(xd).cpu().numpy()
+    ref_l = oracle_mod.truth.log_power(P)
+    # build-defined output (absent from the reference): absolute dB tolerance
+    assert np.max(np.abs(got_l - ref_l)) < 2e-3
+
+
+def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
+    n, hop = 1024, 256
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(n + 300 * hop + 1).astype(np.float32)
+    xd = torch_mod.from_numpy(x).cuda()
+    plan = aa.Stft(n, hop, output="mag")
+    full = plan(xd).cpu().numpy()
+    part = plan.execute_device(xd, 37, 255).cpu().numpy()
+    assert np.array_equal(part, full[37:255])                      # same kernel, same rows
+    # a view that starts 4 bytes into the allocation is not 16-byte aligned -> generic kernel
+    mis = plan.execute_device(xd[1:]).cpu().numpy()
+    ref = oracle_mod.stft(x[1:], n, hop, kind="mag")
+    assert mis.shape == ref.shape
+    assert nerr(mis, ref.astype(np.float64)).max() < TOL_VS_ORACLE
+
+
+# -------------------------------------------------------------------- generic paths --
+@pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 64), (512, 128),
+                                   (1024, 100), (2048, 512), (4096, 1024), (8192, 4096)])
+@pytest.mark.parametrize("output", ["mag", "complex"])
+def test_lds_radix2_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
+    rng = np.random.default_rng(n + hop)
+    x = rng.standard_normal(n + 40 * hop + 1).astype(np.float32)
+    plan = aa.Stft(n, hop, output=output)
+    assert plan.kernel == "lds_radix2"
+    got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle_mod.stft(x, n, hop, kind=output)
+    tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
+    tru = tru if output == "complex" else np.abs(tru)
+    assert got.shape == ref.shape
+    assert nerr(got, ref.astype(tru.dtype)).max() < TOL_VS_ORACLE
+    assert nerr(got, tru).max() < TOL_VS_TRUTH
+
+
+@pytest.mark.parametrize("n,hop", [(6, 2), (12, 5), (100, 25), (1000, 250), (1500, 375)])
+def test_dft_kernel_non_pow2(aa, oracle_mod, torch_mod, n, hop):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n + 20 * hop).astype(np.float32)
+    plan = aa.Stft(n, hop, output="complex")
+    assert plan.kernel == "dft"
+    got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
+    assert got.shape == tru.shape
+    assert nerr(got, tru).max() < TOL_VS_TRUTH
+
+
+def test_windows_rect_and_custom(aa, oracle_mod, torch_mod):
+    n, hop = 512, 128
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n + 10 * hop).astype(np.float32)
+    ones = np.ones(n, np.float32)
+    got = aa.Stft(n, hop, window="rect", output="complex")(x)
+    assert nerr(got, oracle_mod.truth.stft_complex(x, n, hop, ones)).max() < TOL_VS_TRUTH
+    w = rng.uniform(0, 1, n).astype(np.float32)
+    got = aa.Stft(n, hop, window=w, output="complex")(x)
+    assert nerr(got, oracle_mod.truth.stft_complex(x, n, hop, w)).max() < TOL_VS_TRUTH
+    got = aa.Stft(1024, 256, window=w.repeat(2), output="mag")(np.tile(x, 3))
+    ref = np.abs(oracle_mod.truth.stft_complex(np.tile(x, 3), 1024, 256, w.repeat(2)))
+    assert nerr(got, ref).max() < TOL_VS_TRUTH
+
+
+# --------------------------------------------------------- FftProcessor (fft.rs:6-42) --
+@pytest.mark.parametrize("n", [4, 16, 256, 1024, 2048, 8192, 6, 100])
+def test_fft_processor_forward_inverse(aa, oracle_mod, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    fft = aa.FftProcessor(n)
+    X = fft.process_forward(x)
+    T = np.fft.rfft(x.astype(np.float64))
+    assert X.shape == (n // 2 + 1,) and X.dtype == np.complex64
+    assert np.max(np.abs(X - T)) / np.max(np.abs(T)) < TOL_VS_TRUTH
+    assert X[0].imag == 0.0 and X[n // 2].imag == 0.0
+    assert np.max(np.abs(X - oracle_mod.rfft_forward(x))) / np.max(np.abs(T)) < TOL_VS_ORACLE
+    y = fft.process_inverse(X)
+    assert np.max(np.abs(y / n - x)) < 1e-5                          # unnormalised: n * x
+    yo = oracle_mod.rfft_inverse(X, n)
+    assert np.max(np.abs(y - yo)) / np.max(np.abs(yo)) < TOL_VS_ORACLE
+
+
+def test_fft_processor_batch_device(aa, torch_mod):
+    n, batch = 2048, 300
+    g = torch_mod.Generator(device="cuda").manual_seed(1)
+    frames = torch_mod.randn((batch, n), generator=g, device="cuda", dtype=torch_mod.float32)
+    fft = aa.FftProcessor(n)
+    X = fft.forward_batch(frames)
+    T = torch_mod.fft.rfft(frames.double(), dim=-1)
+    err = ((X.to(torch_mod.complex128) - T).abs().amax(dim=1) / T.abs().amax(dim=1)).max().item()
+    assert err < TOL_VS_TRUTH
+    y = fft.inverse_batch(X.contiguous())
+    assert ((y / n - frames).abs().max().item()) < 2e-5
+
+
+def test_fft_processor_length_errors(aa):
+    fft = aa.FftProcessor(256)
+    with pytest.raises(aa.AaError):
+        fft.process_forward(np.zeros(255, np.float32))   # reference: panic (fft.rs:69)
+    with pytest.raises(aa.AaError):
+        fft.process_inverse(np.zeros(128, np.complex64))
+    with pytest.raises(aa.AaError):
+        aa.FftProcessor(255)
+
+
+def test_short_inputs(aa, torch_mod):
+    plan = aa.Stft(1024, 256)
+    assert plan(np.zeros(1023, np.float32)).shape == (0, 513)
+    assert plan(np.ones(1024, np.float32)).shape == (1, 513)
+    assert plan(torch_mod.zeros(1000, device="cuda")).shape == (0, 513)
+
+
+# ------------------------------------------------------------------- streaming front --
+@pytest.mark.parametrize("n,hop,ring", [(2048, 512, 8192), (256, 64, 4096), (1024, 256, 0)])
+def test_stream_matches_oracle_stream(aa, oracle_mod, n, hop, ring):
+    rng = np.random.default_rng(n)
+    pushes = [1024] * 12 + [7000, 1024, 300, 1024]               # 7000 overflows the onset ring
+    x = rng.standard_normal(sum(pushes)).astype(np.float32)
+    eff_ring = ring if ring else max(8192, 4 * n)
+    starts_ref, frames_ref = oracle_mod.stream_frame_starts(pushes, n, hop, eff_ring, slot_data=x,
+                                                            return_frames=True)
+    s = aa.StftStream(n, hop, ring_len=ring, output="mag")
+    rows, starts, pos = [], [], 0
+    for L in pushes:
+        r, st = s.push(x[pos:pos + L])
+        pos += L
+        rows.append(r)
+        starts.append(st)
+    rows, starts = np.concatenate(rows), np.concatenate(starts)
+    assert np.array_equal(starts, starts_ref)                     # bit-exact frame indexing
+    w = oracle_mod.hann_window(n)
+    ref = np.abs(np.fft.rfft((frames_ref * w).astype(np.float32).astype(np.float64), axis=-1))
+    assert rows.shape == ref.shape
+    assert nerr(rows, ref).max() < TOL_VS_TRUTH
+
+
+# ------------------------------------------------- BASELINE full size (config 2) props --
+@pytest.fixture(scope="module")
+def corpus_10min(aa, torch_mod):
+    x = aa.signals.synth_corpus(0, 28_800_000)
+    return x, torch_mod.from_numpy(x).cuda()
+
+
+def test_full_size_frame_count_and_spot_parity(aa, oracle_mod, torch_mod, corpus_10min):
+    x, xd = corpus_10min
+    plan = aa.Stft(1024, 256, output="mag")
+    out = plan(xd)
+    torch_mod.cuda.synchronize()
+    assert out.shape == (112_497, 513)
+    rng = np.random.default_rng(0)
+    idx = np.unique(np.concatenate([[0, 1, 15, 16, 17, 112_495, 112_496],
+                                    rng.integers(0, 112_497, 300)]))
+    got = out[torch_mod.from_numpy(idx).cuda()].cpu().numpy()
+    w = oracle_mod.hann_window(1024)
+    for row, t in zip(got, idx):
+        ref = oracle_mod.stft(x[t * 256:t * 256 + 1024], 1024, 256, kind="mag")[0]
+        tru = np.abs(np.fft.rfft((x[t * 256:t * 256 + 1024] * w).astype(np.float64)))
+        assert nerr(row, ref.astype(np.float64)) < TOL_VS_ORACLE, t
+        assert nerr(row, tru) < TOL_VS_TRUTH, t
+
+
+def test_full_size_parseval(aa, torch_mod, corpus_10min):
+    # sum_k c_k |X_k|^2 = N * sum_i (x_i w_i)^2  (c = 1 for DC/Nyquist, 2 otherwise)
+    _, xd = corpus_10min
+    n, hop = 1024, 256
+    P = aa.Stft(n, hop, output="power")(xd).double()
+    wts = torch_mod.full((513,), 2.0, dtype=torch_mod.float64, device="cuda")
+    wts[0] = wts[512] = 1.0
+    lhs = (P * wts).sum(dim=1)
+    w = torch_mod.from_numpy(aa.hann_window(n)).cuda()
+    fr = xd.unfold(0, n, hop)                                     # [frames, n] view
+    rhs = torch_mod.empty(fr.shape[0], dtype=torch_mod.float64, device="cuda")
+    for s in range(0, fr.shape[0], 16384):
+        blk = (fr[s:s + 16384] * w).double()
+        rhs[s:s + 16384] = n * (blk * blk).sum(dim=1)
+    rel = ((lhs - rhs).abs() / rhs).max().item()
+    assert rel < 1e-5
+
+
+def test_full_size_linearity(aa, torch_mod, corpus_10min):
+    _, xd = corpus_10min
+    n, hop = 1024, 256
+    plan = aa.Stft(n, hop, output="complex")
+    g = torch_mod.Generator(device="cuda").manual_seed(7)
+    yd = torch_mod.rand(xd.shape, generator=g, device="cuda") - 0.5
+    a, b = 0.75, -1.5                                             # exact in f32
+    X, Y = plan(xd), plan(yd)
+    Z = plan(a * xd + b * yd)
+    lin = a * X + b * Y
+    scale = lin.abs().amax(dim=1)
+    err = ((Z - lin).abs().amax(dim=1) / scale).max().item()
+    assert err < TOL_VS_ORACLE
+
+
+def test_full_size_sharded_equals_whole(aa, torch_mod, corpus_10min):
+    """Frame-range shards with the n_fft-hop halo reproduce the single-launch rows
+    bit-for-bit (global frame indexing)."""
+    _, xd = corpus_10min
+    n, hop = 1024, 256
+    plan = aa.Stft(n, hop, output="mag")
+    whole = plan(xd)
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            sp = aa.ShardPlan(xd.shape[0], n, hop, world, r)
+            local = xd[sp.s0:sp.s1].clone()                       # what rank r would hold
+            assert plan.num_frames(local.shape[0]) == sp.local_frames
+            parts.append(plan(local))
+        assert torch_mod.equal(torch_mod.cat(parts), whole)

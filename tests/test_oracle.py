@@ -1,0 +1,112 @@
+"""CPU tests: the C restatement (oracle/) against the float64 truth, the committed golden
+vectors, and the integer framing / ring-buffer rules of the reference."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_GEOMETRIES, GOLDEN_SIGNALS, TOL_VS_TRUTH
+
+
+def test_hann_matches_reference_formula(oracle_mod, golden):
+    # stft.rs:641-648: periodic (denominator n), all f32.
+    for n in (256, 1024, 2048):
+        w = oracle_mod.hann_window(n)
+        assert w.dtype == np.float32 and w.shape == (n,)
+        assert w[0] == 0.0
+        assert abs(w[n // 2] - 1.0) < 1e-6
+        # periodic, not symmetric: w[1] == w[n-1], w[n-1] != 0
+        assert abs(w[1] - w[n - 1]) < 1e-6 and w[n - 1] > 0
+        w64 = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
+        assert np.max(np.abs(w - w64)) < 3e-7
+        # numpy's own f32 evaluation differs by at most a few ulp from libm cosf
+        assert np.max(np.abs(w - oracle_mod.truth.hann_f32(n))) < 2.5e-7
+        assert np.array_equal(w, golden[f"n{n}_window"])
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 64, 256, 512, 1024, 2048, 4096, 8192, 6, 10, 12, 30, 100])
+def test_rfft_forward_vs_numpy_f64(oracle_mod, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    X = oracle_mod.rfft_forward(x)
+    T = np.fft.rfft(x.astype(np.float64))
+    assert X.shape == (n // 2 + 1,)
+    assert np.max(np.abs(X - T)) / np.max(np.abs(T)) < 1e-6
+    # fft.rs contract: X[0] and X[n/2] are purely real
+    assert X[0].imag == 0.0 and X[n // 2].imag == 0.0
+
+
+@pytest.mark.parametrize("n", [4, 16, 256, 1024, 2048, 6, 30])
+def test_rfft_inverse_unnormalised(oracle_mod, n):
+    rng = np.random.default_rng(n + 1)
+    x = rng.standard_normal(n).astype(np.float32)
+    X = oracle_mod.rfft_forward(x)
+    y = oracle_mod.rfft_inverse(X, n)
+    # realfft convention: inverse(forward(x)) = n * x
+    assert np.max(np.abs(y / n - x)) < 5e-6
+
+
+@pytest.mark.parametrize("n,hop", GOLDEN_GEOMETRIES)
+@pytest.mark.parametrize("name", GOLDEN_SIGNALS)
+def test_oracle_vs_golden(oracle_mod, golden, n, hop, name):
+    x = golden[f"n{n}_{name}_x"]
+    T = golden[f"n{n}_{name}_X"]
+    assert T.shape == (oracle_mod.num_frames(len(x), n, hop), n // 2 + 1)
+    C = oracle_mod.stft(x, n, hop, kind="complex")
+    M = oracle_mod.stft(x, n, hop, kind="mag")
+    err = oracle_mod.truth.max_normalised_error
+    if name == "silence":
+        assert not C.any() and not M.any()
+        return
+    assert err(C, T).max() < TOL_VS_TRUTH
+    assert err(M, np.abs(T)).max() < TOL_VS_TRUTH
+
+
+def test_num_frames_rule(oracle_mod):
+    # stft.rs:273, 436-437: while available >= N { ...; available -= hop }
+    nf = oracle_mod.num_frames
+    assert nf(1023, 1024, 256) == 0
+    assert nf(1024, 1024, 256) == 1
+    assert nf(1279, 1024, 256) == 1
+    assert nf(1280, 1024, 256) == 2
+    # BASELINE configs
+    assert nf(28_800_000, 1024, 256) == 112_497
+    assert nf(172_800_000, 1024, 256) == 674_997
+    assert nf(28_800_000, 2048, 512) == 56_247
+    for L, n, h in [(5000, 256, 64), (4097, 2048, 512), (10_000, 1024, 100)]:
+        cnt, avail = 0, L
+        while avail >= n:
+            cnt += 1
+            avail -= h
+        assert nf(L, n, h) == cnt
+
+
+def test_stream_gap_free_equals_batch_framing(oracle_mod):
+    # 1024-sample slots (mod.rs:126-128) through the tuner ring (8192, stft.rs:171)
+    n, hop, ring = 2048, 512, 8192
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(1024 * 40).astype(np.float32)
+    starts, frames = oracle_mod.stream_frame_starts([1024] * 40, n, hop, ring, slot_data=x,
+                                                    return_frames=True)
+    nf = oracle_mod.num_frames(len(x), n, hop)
+    assert np.array_equal(starts, np.arange(nf) * hop)          # bit-exact frame indexing
+    for t in (0, 1, nf // 2, nf - 1):
+        assert np.array_equal(frames[t], x[t * hop:t * hop + n])
+
+
+def test_stream_overflow_drops_oldest(oracle_mod):
+    # stft.rs:262-266: more than ring_len pending -> read position jumps forward
+    n, hop, ring = 256, 64, 4096                                 # onset geometry (onset.rs:122-124)
+    starts = oracle_mod.stream_frame_starts([1024, 6000, 1024], n, hop, ring)
+    # after the first push: frames at 0,64,...; 1024 samples -> (1024-256)/64+1 = 13 frames
+    assert np.array_equal(starts[:13], np.arange(13) * 64)
+    # second push: available = 1024-13*64 + 6000 = 6192 > 4096 -> drop 2096
+    first_after = 13 * 64 + 2096
+    assert starts[13] == first_after
+    assert np.all(np.diff(starts[13:]) == 64)
+
+
+def test_oracle_header_says_parity_unpinned():
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "oracle", "stft_oracle.c")).read()
+    assert "PARITY UNPINNED" in src and "TEST INFRASTRUCTURE ONLY" in src
