@@ -427,8 +427,12 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
 int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
                            int64_t frame_begin, int64_t frame_end, float *out_dev, void *stream)
 {
-    if (!p || !samples_dev || !out_dev)
-        return fail(AA_ERR_ARG, "aa_stft_execute_device: NULL argument");
+    if (!p)
+        return fail(AA_ERR_ARG, "aa_stft_execute_device: plan is NULL");
+    if (frame_begin == frame_end && frame_begin >= 0)
+        return AA_OK;   // nothing to do; buffers may legitimately be empty / NULL
+    if (!samples_dev || !out_dev)
+        return fail(AA_ERR_ARG, "aa_stft_execute_device: NULL buffer");
     const int64_t total = aa_stft_num_frames(p, n_samples);
     if (frame_begin < 0 || frame_end < frame_begin || frame_end > total)
         return fail(AA_ERR_ARG, "frame range [%lld, %lld) outside [0, %lld)", (long long)frame_begin,

@@ -91,9 +91,10 @@ class Stft:
         if out is None:
             out = torch.empty((max(nf, 0), self.cols), dtype=torch.float32, device=samples.device)
         st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
-        _lib.check(self._lib.aa_stft_execute_device(self._plan, samples.data_ptr(),
-                                                    samples.shape[0], frame_begin, frame_end,
-                                                    out.data_ptr(), st))
+        if nf > 0:
+            _lib.check(self._lib.aa_stft_execute_device(self._plan, samples.data_ptr(),
+                                                        samples.shape[0], frame_begin, frame_end,
+                                                        out.data_ptr(), st))
         if self.output == "complex":
             return torch.view_as_complex(out.view(-1, self.cols // 2, 2))
         return out

@@ -102,8 +102,13 @@ def test_wave1024_power_and_logpower(aa, oracle_mod, torch_mod):
     assert nerr(got_p, P).max() < 2 * TOL_VS_TRUTH
     got_l = aa.Stft(n, hop, output="logpower")(xd).cpu().numpy()
     ref_l = oracle_mod.truth.log_power(P)
-    # build-defined output (absent from the reference): absolute dB tolerance
-    assert np.max(np.abs(got_l - ref_l)) < 2e-3
+    # build-defined output (absent from the reference; parity unpinned).  An f32 FFT carries
+    # an absolute error ~1e-7 * frame max, so dB error grows on bins far below the peak:
+    # check (a) the linear-domain criterion after undoing the log and (b) dB agreement on
+    # bins within 40 dB of each frame's maximum.
+    assert nerr(10.0 ** (got_l.astype(np.float64) / 10.0), np.maximum(P, 1e-10)).max() < 4 * TOL_VS_TRUTH
+    near = ref_l >= ref_l.max(axis=1, keepdims=True) - 40.0
+    assert np.max(np.abs(got_l - ref_l)[near]) < 1e-3
 
 
 def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
