@@ -113,16 +113,18 @@ void hann_f32(int n, float *w)
 }
 
 // Per-lane constants of the wave-per-frame 1024 kernel, [kWave1024Rows][64]:
-//   rows  0..15  0.5 * w[2*(64 j + n2) + c]           (row 2j + c),  n2 = 8*(lane&7) + (lane>>3)
+//   rows  0..15  0.5 * w[2*(64 j + n2) + c]           (row 2j + c),  n2 = pass-A point of the lane
 //   rows 16..29  W_512^(n2 k)  re,im   k = 1..7        (pass A twiddles)
 //   rows 30..43  W_64^(b k)    re,im   k = 1..7, b = lane>>3   (pass B twiddles)
 //   rows 44..51  (-sin t, -cos t), t = 2 pi (lane + 64 j)/1024, j = 0..3   (= -i W_1024^k)
-void build_wave1024_table(const float *window, std::vector<float> *tab)
+void build_wave1024_table(const float *window, bool natural, std::vector<float> *tab)
 {
     tab->assign((size_t)aa::kWave1024Rows * 64, 0.0f);
     float *T = tab->data();
     for (int lane = 0; lane < 64; ++lane) {
-        const int n2 = 8 * (lane & 7) + (lane >> 3);
+        // pass-A point index of the lane: variant 3 reads m = 64 j + lane, variants 1/2
+        // m = 64 j + 8*(lane&7) + (lane>>3)
+        const int n2 = natural ? lane : 8 * (lane & 7) + (lane >> 3);
         const int b = lane >> 3;
         for (int j = 0; j < 8; ++j)
             for (int c = 0; c < 2; ++c)
@@ -361,19 +363,18 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
         int r = build_fft_tables(cfg->n_fft, &p->tabs);
         if (r != AA_OK)
             return r;
-        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
-            // frames per workgroup: as many as fit the LDS budget, capped by the tunable.
-            int want = 16;
+        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0 &&
+            (aa::wave1024_variant() != 4 || cfg->hop % 2 == 0)) {
+            // frames per workgroup: the tunable default, shrunk until the LDS need fits 64 KiB.
+            const int variant = aa::wave1024_variant();
+            int fpw = variant == 3 ? 8 : 16;
             if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))
-                want = std::atoi(s) > 0 ? std::atoi(s) : want;
-            const int64_t budget_dwords = 16384 - 4 * aa::kWave1024XchDwords;  // 64 KiB total
-            int fpw = 1;
-            while (fpw < want &&
-                   aa::wave1024_stage_dwords(fpw * cfg->hop + 1024) <= budget_dwords)
-                ++fpw;
-            if (aa::wave1024_stage_dwords((fpw - 1) * cfg->hop + 1024) <= budget_dwords) {
+                fpw = std::atoi(s) > 0 ? std::atoi(s) : fpw;
+            while (fpw > 1 && aa::wave1024_lds_dwords(fpw, cfg->hop, variant) > 16384)
+                --fpw;
+            if (aa::wave1024_lds_dwords(fpw, cfg->hop, variant) <= 16384) {
                 std::vector<float> tab;
-                build_wave1024_table(p->window_host.data(), &tab);
+                build_wave1024_table(p->window_host.data(), variant >= 3, &tab);
                 AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
                                  hipMemcpyHostToDevice));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 namespace aa {
 
@@ -17,10 +18,35 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024XchDwords = 520;            // per-wave split exchange area
 // LDS dwords needed to stage `span` samples in the padded layout (+8 per 64).
 inline int wave1024_stage_dwords(int span) { return span + 8 * ((span + 63) / 64); }
-inline size_t wave1024_lds_bytes(int frames_per_wg, int hop)
+// Kernel variant: 4 (default) = barrier-free streaming, samples prefetched into VGPRs;
+// 3 = persistent, LDS-DMA double-buffered staging, first exchange
+// through LDS; 2 = one-shot workgroups, first exchange through LDS; 1 = one-shot, all-register
+// exchanges.  AA_W1024_VARIANT overrides (A/B runs only).
+inline int wave1024_variant()
 {
-    int span = (frames_per_wg - 1) * hop + 1024;
-    return sizeof(float) * (size_t)(wave1024_stage_dwords(span) + 4 * kWave1024XchDwords);
+    static const int v = [] {
+        const char *s = std::getenv("AA_W1024_VARIANT");
+        if (s && s[0] >= '1' && s[0] <= '4')
+            return s[0] - '0';
+        return 4;
+    }();
+    return v;
+}
+constexpr int kWave1024ScratchDwordsV2 = 1152;     // per-wave E1 scratch / split strip (v2)
+constexpr int kWave1024ScratchDwordsV3 = 1056;     // same, natural lane mapping (v3)
+// LDS dwords a workgroup needs for `frames_per_wg` frames.
+inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int variant)
+{
+    const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
+    if (variant == 4)
+        return 4 * kWave1024ScratchDwordsV3;                             // scratch only
+    if (variant == 3)
+        return 2 * span + 4 * kWave1024ScratchDwordsV3;                  // double buffer, unpadded
+    return span + 8 * ((span + 63) / 64) + 4 * (variant == 1 ? kWave1024XchDwords : kWave1024ScratchDwordsV2);
+}
+inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int variant)
+{
+    return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop, variant);
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,

@@ -13,7 +13,75 @@
 namespace aa {
 namespace {
 
+// In-kernel phase stamps (diagnostic builds only: tools/stamp_w1024.hip defines AA_STAMPS;
+// the shipped library never executes a stamp).  acc[i] += cycles since the previous stamp.
+#ifdef AA_STAMPS
+#define AA_STAMP_DECL unsigned long long st_prev_ = 0, st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define AA_STAMP(i)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long t_;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        st_acc_[i] += t_ - st_prev_;                                                         \
+        st_prev_ = t_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define AA_STAMP_DUMP(dbg)                                                                   \
+    if (lane == 0)                                                                           \
+        for (int i_ = 0; i_ < 12; ++i_)                                                      \
+            (dbg)[((size_t)blockIdx.x * 4 + wave) * 12 + i_] = st_acc_[i_];
+#else
+#define AA_STAMP_DECL
+#define AA_STAMP(i)
+#define AA_STAMP_DUMP(dbg)
+#endif
+
+// Clock probe for tools/ablate_w1024.hip (diagnostic builds only): shader cycles and
+// 100 MHz real-time ticks spent by each workgroup's wave 0.
+#ifdef AA_ABLATE
+__device__ unsigned long long aa_clk_dbg[4 * 8192];
+#define AA_CLK_BEGIN                                                                         \
+    unsigned long long clk_t0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime();
+#define AA_CLK_END                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                             \
+        aa_clk_dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0_;                 \
+        aa_clk_dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0_;         \
+        aa_clk_dbg[4 * blockIdx.x + 2] = clk_r0_;                                            \
+        unsigned xcc_;                                                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                  \
+        unsigned hwid_;                                                                      \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));                  \
+        aa_clk_dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc_ << 32) | hwid_;           \
+    }
+#else
+#define AA_CLK_BEGIN
+#define AA_CLK_END
+#endif
+
 // ------------------------------------------------------------------ helpers --
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 32-bit LDS byte address of a __shared__ object (for hand-issued DS instructions).
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+// One ds_read_b64 that the load/store optimizer cannot fuse into ds_read2_b64 (which
+// costs 8 LDS cycles per pair instead of 2+2 and banks on 32 instead of 64 banks —
+// profiles/r01_ubench_valu_gfx950.txt).  The result is valid after lds_wait_*().
+template <int BYTE_OFF>
+__device__ __forceinline__ v2f lds_read_b64(unsigned addr)
+{
+    v2f r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(BYTE_OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait_8(v2f &a, v2f &b, v2f &c, v2f &d, v2f &e, v2f &f, v2f &g, v2f &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
@@ -288,6 +356,563 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     }
 }
 
+// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 2 --
+// Same decomposition as stft_wave1024_kernel, but the first exchange (registers <-> lane
+// bits 0-2) goes through a wave-private LDS scratch instead of DPP + select: measured on
+// gfx950 (profiles/r01_ubench_valu_gfx950.txt) v_cndmask_b32 costs 12-19 cycles and a DPP
+// move 3-4, while the LDS pipe sat at 16 % — the kernel was VALU-bound on data movement.
+//   write  lane (a,b) stores Y[k1] at complex address 72 b + 8 k1 + a        (ds_write_b64,
+//          16 consecutive lanes cover 32 banks -> conflict free)
+//   read   lane (k1,b) loads a = 0..7 from 72 b + 8 k1 + a as 4 x ds_read_b128; the skew
+//          72 = 64 + 8 makes the sixteen 16-byte slots of every b128 lane group distinct.
+// The same scratch is reused as the split strip.  The second exchange (lane bits 3-5) stays
+// in registers: row_ror:8 DPP moves with bank masks and v_permlane{16,32}_swap need no select.
+constexpr int kW1024ScratchDwords = 1152;   // 568 complex, rounded up
+
+template <int OUT>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v2_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, float log_floor)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+
+    const int64_t f0 = (int64_t)chunk * frames_per_wg;
+    const int64_t left = n_frames - f0;
+    const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+    const float *src = x + (frame_begin + f0) * (int64_t)hop;
+    const int span4 = ((nf - 1) * hop + 1024) >> 2;
+    const int max_span = (frames_per_wg - 1) * hop + 1024;
+    float2 *scr = reinterpret_cast<float2 *>(smem + (max_span + 8 * ((max_span + 63) >> 6)) +
+                                             wave * kW1024ScratchDwords);
+
+    for (int q = tid; q < span4; q += kWave1024Threads) {
+        float4 s = reinterpret_cast<const float4 *>(src)[q];
+        *reinterpret_cast<float4 *>(&smem[4 * q + 8 * (q >> 4)]) = s;
+    }
+
+    float win[16];
+    float2 twA[8], twB[8], tws[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        win[i] = tab[i * 64 + lane];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
+        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
+
+    const int la = lane & 7, lb = lane >> 3;
+    const int n2 = 8 * la + lb;
+    const int lane_off = 2 * n2 + 8 * (n2 >> 5);
+    const unsigned smem_addr = lds_addr(smem);
+    float2 *e1_wr = scr + 72 * lb + la;                                     // + 8 k1
+    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 72 * lb + 8 * la);
+    constexpr int NB = 513;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+
+    __syncthreads();
+
+    for (int t = wave; t < nf; t += 4) {
+        const int fb = t * hop;
+        const unsigned fr = smem_addr + 4u * (unsigned)(fb + (fb >> 3) + lane_off);
+        float2 v[8];
+        {
+            v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<576>(fr), s2 = lds_read_b64<1152>(fr),
+                s3 = lds_read_b64<1728>(fr), s4 = lds_read_b64<2304>(fr), s5 = lds_read_b64<2880>(fr),
+                s6 = lds_read_b64<3456>(fr), s7 = lds_read_b64<4032>(fr);
+            lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
+            v[0] = make_float2(s0.x * win[0], s0.y * win[1]);
+            v[1] = make_float2(s1.x * win[2], s1.y * win[3]);
+            v[2] = make_float2(s2.x * win[4], s2.y * win[5]);
+            v[3] = make_float2(s3.x * win[6], s3.y * win[7]);
+            v[4] = make_float2(s4.x * win[8], s4.y * win[9]);
+            v[5] = make_float2(s5.x * win[10], s5.y * win[11]);
+            v[6] = make_float2(s6.x * win[12], s6.y * win[13]);
+            v[7] = make_float2(s7.x * win[14], s7.y * win[15]);
+        }
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            v[k] = cmul(v[k], twA[k]);
+        // ---- E1 through LDS ----
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            e1_wr[8 * k] = v[k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 qv = e1_rd[i];
+            v[2 * i] = make_float2(qv.x, qv.y);
+            v[2 * i + 1] = make_float2(qv.z, qv.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            v[k] = cmul(v[k], twB[k]);
+        exchange_high(v);
+        dft8(v);
+
+        // ---- split ----
+#pragma unroll
+        for (int j = 4; j < 8; ++j)
+            scr[lane + 64 * (j - 4)] = v[j];
+        if (lane == 0)
+            scr[256] = v[0];
+        __builtin_amdgcn_wave_barrier();
+        float *row = out + (f0 + t) * (int64_t)COLS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            float2 a = v[j];
+            float2 p = scr[256 - k];
+            float2 bc = make_float2(p.x, -p.y);
+            float2 e = cadd(a, bc), o = csub(a, bc);
+            float2 tt = cmul(o, tws[j]);
+            float2 xk = cadd(e, tt);
+            float2 xm = csub(e, tt);
+            if (OUT == kComplex) {
+                reinterpret_cast<float2 *>(row)[k] = xk;
+                reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
+            } else {
+                row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
+                row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
+            }
+        }
+        if (lane == 0) {
+            float2 z = v[4];
+            if (OUT == kComplex)
+                reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
+            else
+                row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 3 --
+// Persistent, software-pipelined form of variant 2 (the shipped default):
+//   * a workgroup owns a contiguous run of chunks (frames_per_wg frames each) and loops
+//     over them; the per-lane constant table is loaded once per workgroup, not per chunk;
+//   * the samples of chunk c+1 are fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+//     into the other half of a double buffer while chunk c is transformed;
+//   * staging is unpadded (DMA writes 1 KiB contiguous per wave instruction): pass A uses
+//     the natural mapping lane = n2 (m = 64 j + lane), conflict-free for ds_read_b64;
+//   * E1 scratch addressing for that mapping: writer lane (a = l>>3, b = l&7) stores Y[k1]
+//     at complex 66 b + 8 k1 + a, reader lane (k1 = L&7, b = L>>3) loads 8 consecutive
+//     complex from 66 b + 8 k1 (4 x ds_read_b128); both sides are bank-conflict free.
+constexpr int kW1024ScratchDwordsV3 = 1056;   // 526 complex, rounded up to 16 B
+
+// ABL: ablation mask for tools/ablate_w1024.hip (diagnostic; 0 in the shipped library):
+//   1 no global stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split strip,
+//   32 no per-chunk barrier/vmcnt wait
+template <int OUT, int ABL = 0, bool WIDE = false>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v3_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
+    float log_floor
+#ifdef AA_STAMPS
+    , unsigned long long *dbg
+#endif
+    )
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
+    const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
+    const int max_span = (frames_per_wg - 1) * hop + 1024;          // floats, multiple of 64
+    float2 *scr = reinterpret_cast<float2 *>(smem + 2 * max_span + wave * kW1024ScratchDwordsV3);
+
+    // LDS-DMA of one chunk's samples into buffer `which` (wave w moves 1 KiB pieces w, w+4, ..)
+    auto stage = [&](int64_t c, int which) {
+        const int64_t f0 = c * frames_per_wg;
+        const int64_t left = n_frames - f0;
+        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+        const int span4 = ((nf - 1) * hop + 1024) >> 2;
+        const float *src = x + (frame_begin + f0) * (int64_t)hop;
+        float *dst = smem + which * max_span;
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+            const int q = qb + lane;
+            if (q < span4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + 4 * (int64_t)q),
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+        }
+    };
+
+    if (c0 < c1)
+        stage(c0, 0);
+
+    float win[16];
+    float2 twA[8], twB[8], tws[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        win[i] = tab[i * 64 + lane];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
+        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
+
+    const unsigned smem_addr = lds_addr(smem);
+    float2 *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
+    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    constexpr int NB = 513;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+
+    AA_STAMP_DECL
+    AA_STAMP(0);   // 0: prologue (first DMA issue + table loads)
+    for (int64_t c = c0; c < c1; ++c) {
+        const int cur = (int)(c - c0) & 1;
+        // chunk c has landed (this wave's DMA) and every wave is done with chunk c-1
+        if (!(ABL & 32) || c == c0) {
+            // vmcnt retires in issue order and counts stores: the DMA of chunk c is older than
+            // every row store of chunk c-1 (9 per frame), so waiting down to that many
+            // outstanding operations covers the DMA without waiting for the store acks.
+            if ((ABL & 64) || c == c0 || frames_per_wg != 8)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            AA_STAMP(1);   // 1: vmcnt wait (DMA of this chunk)
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        AA_STAMP(2);   // 2: barrier
+        if (c + 1 < c1 && !(ABL & 8))
+            stage(c + 1, cur ^ 1);
+        AA_STAMP(3);   // 3: DMA issue
+
+        const int64_t f0 = c * frames_per_wg;
+        const int64_t left = n_frames - f0;
+        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
+
+        for (int t = wave; t < nf; t += 4) {
+            const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
+            float2 v[8];
+            {
+                v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<512>(fr), s2 = lds_read_b64<1024>(fr),
+                    s3 = lds_read_b64<1536>(fr), s4 = lds_read_b64<2048>(fr), s5 = lds_read_b64<2560>(fr),
+                    s6 = lds_read_b64<3072>(fr), s7 = lds_read_b64<3584>(fr);
+                lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
+                AA_STAMP(4);   // 4: frame ds_read_b64 x8 + wait
+                v[0] = make_float2(s0.x * win[0], s0.y * win[1]);
+                v[1] = make_float2(s1.x * win[2], s1.y * win[3]);
+                v[2] = make_float2(s2.x * win[4], s2.y * win[5]);
+                v[3] = make_float2(s3.x * win[6], s3.y * win[7]);
+                v[4] = make_float2(s4.x * win[8], s4.y * win[9]);
+                v[5] = make_float2(s5.x * win[10], s5.y * win[11]);
+                v[6] = make_float2(s6.x * win[12], s6.y * win[13]);
+                v[7] = make_float2(s7.x * win[14], s7.y * win[15]);
+            }
+            dft8(v);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                v[k] = cmul(v[k], twA[k]);
+            AA_STAMP(5);   // 5: window + pass A + twiddle
+            // ---- E1 through LDS ----
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    e1_wr[8 * k] = v[k];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 qv = e1_rd[i];
+                    v[2 * i] = make_float2(qv.x, qv.y);
+                    v[2 * i + 1] = make_float2(qv.z, qv.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            AA_STAMP(6);   // 6: E1 writes + reads + wait
+            dft8(v);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                v[k] = cmul(v[k], twB[k]);
+            AA_STAMP(7);   // 7: pass B + twiddle
+            if (!(ABL & 2))
+                exchange_high(v);
+            AA_STAMP(8);   // 8: E2 (DPP + permlane swaps)
+            dft8(v);
+            AA_STAMP(9);   // 9: pass C
+
+            // ---- split ----
+            float2 prt[4];
+            if (!(ABL & 16)) {
+#pragma unroll
+                for (int j = 4; j < 8; ++j)
+                    scr[lane + 64 * (j - 4)] = v[j];
+                if (lane == 0)
+                    scr[256] = v[0];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    prt[j] = scr[256 - (lane + 64 * j)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    prt[j] = v[7 - j];
+            }
+            float *row = out + (f0 + t) * (int64_t)COLS;
+            AA_STAMP(10);  // 10: split strip writes + reads + wait
+            if (WIDE && OUT != kComplex && !(ABL & 1)) {
+                // Row through LDS so it leaves as 16-byte-aligned nontemporal dwordx4 stores:
+                // on gfx950 this R:W mix moves 6.2 TB/s that way against 4.5-4.7 TB/s with
+                // plain dword or dwordx4 stores (tools/ubench_rw2.hip).  The row starts at
+                // float 513 r of a 16-byte-aligned buffer, so its aligned window begins
+                // sh = r & 3 floats earlier; LDS float i <-> global float 513 r - sh + i.
+                const int sh = (int)((f0 + t) & 3);
+                float *lrow = reinterpret_cast<float *>(scr) + sh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    float2 a = v[j];
+                    float2 p = prt[j];
+                    float2 bc = make_float2(p.x, -p.y);
+                    float2 e = cadd(a, bc), o = csub(a, bc);
+                    float2 tt = cmul(o, tws[j]);
+                    float2 xk = cadd(e, tt);
+                    float2 xm = csub(e, tt);
+                    lrow[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
+                    lrow[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
+                }
+                if (lane == 0)
+                    lrow[256] = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+                __builtin_amdgcn_wave_barrier();
+                const float *lw = reinterpret_cast<const float *>(scr);
+                float *gw = row - sh;                                   // 16-byte aligned
+                v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                if (lane < 63) {
+                    v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * lane);
+                    __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                }
+                // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
+                const int hi = lane < 4 ? lane : 508 + lane;
+                const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
+                if (ok)
+                    gw[hi] = lw[hi];
+            } else {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    float2 a = v[j];
+                    float2 p = prt[j];
+                    float2 bc = make_float2(p.x, -p.y);
+                    float2 e = cadd(a, bc), o = csub(a, bc);
+                    float2 tt = cmul(o, tws[j]);
+                    float2 xk = cadd(e, tt);
+                    float2 xm = csub(e, tt);
+                    if (ABL & 1) {
+                        float r0 = bin_value<OUT>(xk.x, xk.y, log_floor), r1 = bin_value<OUT>(xm.x, xm.y, log_floor);
+                        asm volatile("" ::"v"(r0), "v"(r1));
+                    } else if (OUT == kComplex) {
+                        reinterpret_cast<float2 *>(row)[k] = xk;
+                        reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
+                    } else {
+                        row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
+                        row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
+                    }
+                }
+                if (lane == 0 && !(ABL & 1)) {
+                    float2 z = v[4];
+                    if (OUT == kComplex)
+                        reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
+                    else
+                        row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            AA_STAMP(11);  // 11: split math + magnitude + stores
+        }
+    }
+    AA_STAMP_DUMP(dbg)
+}
+
+// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 4 --
+// Barrier-free streaming form: every wave is independent.  A workgroup (4 waves) owns a
+// contiguous run of frames and wave w takes frames run_begin + 4 i + w, so the four waves
+// read overlapping samples at about the same time (served by L1/L2; HBM sees each sample
+// once) — no LDS staging, no DMA, no __syncthreads.  The samples of the wave's NEXT frame
+// are prefetched straight into VGPRs (8 x global_load_dwordx2, 512 B per instruction,
+// m = 64 j + lane) before the current frame is transformed; the compiler's counted vmcnt
+// lets the 9 row stores of the previous frame stay in flight.  LDS holds only the
+// wave-private E1 / split scratch.  Ablation on gfx950 (tools/ablate_w1024.hip) showed the
+// LDS-DMA + barrier structure of variant 3 serialising memory phases against compute.
+template <int OUT, int ABL = 0>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v4_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, float log_floor)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    AA_CLK_BEGIN
+
+    // frames [r0, r1) of this workgroup; wave w: r0 + w, r0 + w + 4, ...
+    const int64_t r0 = (int64_t)blockIdx.x * n_frames / gridDim.x;
+    const int64_t r1 = (int64_t)(blockIdx.x + 1) * n_frames / gridDim.x;
+    float2 *scr = reinterpret_cast<float2 *>(smem + wave * kW1024ScratchDwordsV3);
+
+    float win[16];
+    float2 twA[8], twB[8], tws[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        win[i] = tab[i * 64 + lane];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
+        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
+
+    float2 *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
+    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    constexpr int NB = 513;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+
+    int64_t t = r0 + wave;
+    if (t >= r1)
+        return;
+    const float2 *src = reinterpret_cast<const float2 *>(x + (frame_begin + t) * (int64_t)hop) + lane;
+    const int64_t src_step = 2 * (int64_t)hop;          // float2 units per 4 frames
+
+    // one frame: windowed samples in `v` -> row t of the output
+    auto transform = [&](float2 (&v)[8], int64_t tt) {
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            v[k] = cmul(v[k], twA[k]);
+        // ---- E1 through LDS ----
+        if (!(ABL & 4)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                e1_wr[8 * k] = v[k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 qv = e1_rd[i];
+                v[2 * i] = make_float2(qv.x, qv.y);
+                v[2 * i + 1] = make_float2(qv.z, qv.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            v[k] = cmul(v[k], twB[k]);
+        if (!(ABL & 2))
+            exchange_high(v);
+        dft8(v);
+
+        // ---- split ----
+        float2 prt[4];
+        if (!(ABL & 16)) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j)
+                scr[lane + 64 * (j - 4)] = v[j];
+            if (lane == 0)
+                scr[256] = v[0];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                prt[j] = scr[256 - (lane + 64 * j)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                prt[j] = v[7 - j];
+        }
+        float *row = out + tt * (int64_t)COLS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            float2 a = v[j];
+            float2 p = prt[j];
+            float2 bc = make_float2(p.x, -p.y);
+            float2 e = cadd(a, bc), o = csub(a, bc);
+            float2 tt2 = cmul(o, tws[j]);
+            float2 xk = cadd(e, tt2);
+            float2 xm = csub(e, tt2);
+            if (ABL & 1) {
+                float q0 = bin_value<OUT>(xk.x, xk.y, log_floor), q1 = bin_value<OUT>(xm.x, xm.y, log_floor);
+                asm volatile("" ::"v"(q0), "v"(q1));
+            } else if (OUT == kComplex) {
+                reinterpret_cast<float2 *>(row)[k] = xk;
+                reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
+            } else {
+                row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
+                row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
+            }
+        }
+        if (lane == 0 && !(ABL & 1)) {
+            float2 z = v[4];
+            if (OUT == kComplex)
+                reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
+            else
+                row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // Prefetch distance 2: vmcnt completes in issue order and counts stores, so a load only
+    // returns after every older store of the wave has been acknowledged; keeping the awaited
+    // loads two frames older than the newest stores takes the store latency off the path.
+    float2 bufA[8], bufB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        bufA[j] = src[64 * j];
+    if (t + 4 < r1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            bufB[j] = src[src_step + 64 * j];
+    }
+    src += 2 * src_step;
+    for (; t < r1; t += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = make_float2(bufA[j].x * win[2 * j], bufA[j].y * win[2 * j + 1]);
+        if (t + 8 < r1 && !(ABL & 8)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                bufA[j] = src[64 * j];
+        }
+        transform(v, t);
+        if (t + 4 >= r1)
+            break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = make_float2(bufB[j].x * win[2 * j], bufB[j].y * win[2 * j + 1]);
+        if (t + 12 < r1 && !(ABL & 8)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                bufB[j] = src[src_step + 64 * j];
+        }
+        transform(v, t + 4);
+        src += 2 * src_step;
+    }
+    AA_CLK_END
+}
+
 // ------------------------------------------------------- generic forward paths --
 __device__ __forceinline__ float2 split_tw(const float2 *tw_split, int k, int m)
 {
@@ -491,6 +1116,24 @@ __global__ void irfft_kernel(const float *__restrict__ spec, float *__restrict__
 }  // namespace
 
 // ------------------------------------------------------------------- launchers --
+#if !defined(AA_STAMPS) && !defined(AA_ABLATE)   // diagnostic builds drive the kernels themselves
+// Persistent grid for variant 3: resident workgroups per CU (occupancy API) x CUs.
+template <typename K>
+static int persistent_grid(K kernel, size_t lds, int64_t n_chunks)
+{
+    int dev = 0, cus = 256, per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave1024Threads, lds) != hipSuccess ||
+        per_cu < 1)
+        per_cu = 1;
+    int64_t g = (int64_t)cus * per_cu;
+    return (int)(g < n_chunks ? g : n_chunks);
+}
+
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream)
@@ -498,18 +1141,80 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     if (n_frames <= 0)
         return hipSuccess;
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop);
+    const int variant = wave1024_variant();
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, variant);
     dim3 grid((unsigned)chunks), block(kWave1024Threads);
-#define AA_LAUNCH_W1024(K)                                                                     \
-    hipLaunchKernelGGL((stft_wave1024_kernel<K>), grid, block, lds, stream, x, out, table,     \
-                       frame_begin, n_frames, hop, frames_per_wg, log_floor)
-    switch (out_kind) {
-    case kComplex: AA_LAUNCH_W1024(kComplex); break;
-    case kMag: AA_LAUNCH_W1024(kMag); break;
-    case kPower: AA_LAUNCH_W1024(kPower); break;
-    case kLogPower: AA_LAUNCH_W1024(kLogPower); break;
-    default: return hipErrorInvalidValue;
+    // aligned nontemporal row stores need a 16-byte-aligned output buffer (AA_W1024_WIDE=0: A/B)
+    static const bool wide_env = [] { const char *e = std::getenv("AA_W1024_WIDE"); return !(e && e[0] == '0'); }();
+    const bool wide = wide_env && out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+#define AA_LAUNCH_W1024(KERNEL, K)                                                             \
+    hipLaunchKernelGGL((KERNEL<K>), grid, block, lds, stream, x, out, table, frame_begin,      \
+                       n_frames, hop, frames_per_wg, log_floor)
+#define AA_SWITCH_W1024(KERNEL)                                                                \
+    switch (out_kind) {                                                                        \
+    case kComplex: AA_LAUNCH_W1024(KERNEL, kComplex); break;                                   \
+    case kMag: AA_LAUNCH_W1024(KERNEL, kMag); break;                                           \
+    case kPower: AA_LAUNCH_W1024(KERNEL, kPower); break;                                       \
+    case kLogPower: AA_LAUNCH_W1024(KERNEL, kLogPower); break;                                 \
+    default: return hipErrorInvalidValue;                                                      \
     }
+#define AA_LAUNCH_W1024_V3(K)                                                                  \
+    {                                                                                          \
+        static int cached_grid = 0;                                                            \
+        static size_t cached_lds = 0;                                                          \
+        if (cached_grid == 0 || cached_lds != lds) {                                           \
+            cached_grid = persistent_grid(stft_wave1024_v3_kernel<K>, lds, 1 << 30);           \
+            cached_lds = lds;                                                                  \
+        }                                                                                      \
+        int64_t g = cached_grid < chunks ? cached_grid : chunks;                               \
+        if (wide)                                                                              \
+            hipLaunchKernelGGL((stft_wave1024_v3_kernel<K, 0, true>), dim3((unsigned)g), block,    \
+                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
+                               frames_per_wg, chunks, log_floor);                              \
+        else                                                                                   \
+            hipLaunchKernelGGL((stft_wave1024_v3_kernel<K, 0, false>), dim3((unsigned)g), block,   \
+                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
+                               frames_per_wg, chunks, log_floor);                              \
+    }
+    if (variant == 4) {
+        const size_t lds4 = sizeof(float) * 4 * kW1024ScratchDwordsV3;
+        static int grid4 = 0;
+        if (grid4 == 0)
+            grid4 = persistent_grid(stft_wave1024_v4_kernel<kMag>, lds4, 1 << 30);
+        const int64_t groups = (n_frames + 3) / 4;
+        const unsigned g = (unsigned)(grid4 < groups ? grid4 : groups);
+        const float *xs = x;
+        float *outs = out;
+        switch (out_kind) {
+        case kComplex:
+            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kComplex>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
+            break;
+        case kMag:
+            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kMag>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
+            break;
+        case kPower:
+            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kPower>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
+            break;
+        case kLogPower:
+            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kLogPower>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
+            break;
+        default: return hipErrorInvalidValue;
+        }
+    } else if (variant == 1) {
+        AA_SWITCH_W1024(stft_wave1024_kernel)
+    } else if (variant == 2) {
+        AA_SWITCH_W1024(stft_wave1024_v2_kernel)
+    } else {
+        switch (out_kind) {
+        case kComplex: AA_LAUNCH_W1024_V3(kComplex); break;
+        case kMag: AA_LAUNCH_W1024_V3(kMag); break;
+        case kPower: AA_LAUNCH_W1024_V3(kPower); break;
+        case kLogPower: AA_LAUNCH_W1024_V3(kLogPower); break;
+        default: return hipErrorInvalidValue;
+        }
+    }
+#undef AA_LAUNCH_W1024_V3
+#undef AA_SWITCH_W1024
 #undef AA_LAUNCH_W1024
     return hipGetLastError();
 }
@@ -563,5 +1268,7 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
         hipLaunchKernelGGL((irfft_kernel<false>), grid, block, lds, stream, spec, out, twm, tws, n);
     return hipGetLastError();
 }
+
+#endif  // !AA_STAMPS && !AA_ABLATE
 
 }  // namespace aa

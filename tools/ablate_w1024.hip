@@ -1,0 +1,131 @@
+// Diagnostic (never shipped): times the v3 kernel with parts removed (outputs are wrong by
+// construction; only the time matters) to find what the real pipeline is bound by.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DAA_ABLATE -I audio_analyzer_rs_amd/csrc -o tools/bin/ablate_w1024 tools/ablate_w1024.hip
+#include "aa_kernels.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+
+static float *dx, *dout, *dtab;
+static const int hop = 256;
+static const int64_t n_samples = 28800000, n_frames = (n_samples - 1024) / hop + 1;
+
+template <int ABL>
+double run(int fpw, const char *name)
+{
+    const int64_t chunks = (n_frames + fpw - 1) / fpw;
+    const size_t lds = aa::wave1024_lds_bytes(fpw, hop, 3);
+    int per_cu = 1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v3_kernel<aa::kMag, ABL>, 256, lds);
+    int grid = 256 * per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> ts;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i)
+            hipLaunchKernelGGL((aa::stft_wave1024_v3_kernel<aa::kMag, ABL>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        ts.push_back(ms / 20);
+    }
+    std::sort(ts.begin(), ts.end());
+    printf("fpw %2d  %-44s %d WG/CU  median %.2f us  min %.2f us\n", fpw, name, per_cu, ts[ts.size() / 2] * 1e3, ts[0] * 1e3);
+    return ts[ts.size() / 2];
+}
+
+template <int ABL>
+double run4(const char *name, int wgs_per_cu = 0)
+{
+    const size_t lds = sizeof(float) * 4 * aa::kW1024ScratchDwordsV3;
+    int per_cu = 1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v4_kernel<aa::kMag, ABL>, 256, lds);
+    if (wgs_per_cu > 0) per_cu = wgs_per_cu;
+    int grid = 256 * per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> ts;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i)
+            hipLaunchKernelGGL((aa::stft_wave1024_v4_kernel<aa::kMag, ABL>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+                               (int64_t)0, n_frames, hop, 1e-10f);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        ts.push_back(ms / 20);
+    }
+    std::sort(ts.begin(), ts.end());
+    std::vector<unsigned long long> clk(4 * 8192);
+    hipMemcpyFromSymbol(clk.data(), HIP_SYMBOL(aa::aa_clk_dbg), clk.size() * 8);
+    std::vector<double> ghz, life, start;
+    unsigned long long first = ~0ull;
+    int nb = grid < 8192 ? grid : 8192;
+    for (int b = 0; b < nb; ++b) first = std::min(first, clk[4 * b + 2]);
+    int per_xcc[16] = {0};
+    for (int b = 0; b < nb; ++b) {
+        ghz.push_back((double)clk[4 * b] / (double)clk[4 * b + 1] * 0.1);
+        life.push_back(clk[4 * b + 1] * 0.01);
+        start.push_back((clk[4 * b + 2] - first) * 0.01);
+        per_xcc[(clk[4 * b + 3] >> 32) & 15]++;
+    }
+    std::sort(ghz.begin(), ghz.end()); std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end());
+    printf("v4      %-40s %d WG/CU  median %.2f us  clock %.2f GHz  WG life min/med/max %.1f/%.1f/%.1f us  start med/p90/max %.1f/%.1f/%.1f us  xcc:", name, per_cu,
+           ts[ts.size() / 2] * 1e3, ghz[nb / 2], life[0], life[nb / 2], life[nb - 1], start[nb / 2], start[nb * 9 / 10], start[nb - 1]);
+    for (int i = 0; i < 8; ++i) printf(" %d", per_xcc[i]);
+    printf("\n");
+    return ts[ts.size() / 2];
+}
+
+int main(int argc, char **argv)
+{
+    const int fpw = argc > 1 ? atoi(argv[1]) : 8;
+    std::vector<float> hx(n_samples), win(1024), tab(52 * 64);
+    unsigned s = 12345;
+    for (auto &v : hx) { s = (s * 1103515245u + 12345u) & 0x7fffffffu; v = (float)s / 1073741824.0f - 1.0f; }
+    for (int i = 0; i < 1024; ++i) win[i] = 0.5f - 0.5f * cosf(2.0f * 3.14159265f * i / 1024.0f);
+    const double kPi = 3.14159265358979323846;
+    for (int lane = 0; lane < 64; ++lane) {
+        int n2 = lane, b = lane >> 3;
+        for (int j = 0; j < 8; ++j) for (int c = 0; c < 2; ++c) tab[(2 * j + c) * 64 + lane] = 0.5f * win[2 * (64 * j + n2) + c];
+        for (int k = 1; k < 8; ++k) {
+            double aA = -2.0 * kPi * (n2 * k) / 512.0, aB = -2.0 * kPi * (b * k) / 64.0;
+            tab[(16 + 2 * (k - 1)) * 64 + lane] = cos(aA); tab[(17 + 2 * (k - 1)) * 64 + lane] = sin(aA);
+            tab[(30 + 2 * (k - 1)) * 64 + lane] = cos(aB); tab[(31 + 2 * (k - 1)) * 64 + lane] = sin(aB);
+        }
+        for (int j = 0; j < 4; ++j) { double th = 2.0 * kPi * (lane + 64 * j) / 1024.0; tab[(44 + 2 * j) * 64 + lane] = -sin(th); tab[(45 + 2 * j) * 64 + lane] = -cos(th); }
+    }
+    hipMalloc(&dx, n_samples * 4); hipMalloc(&dout, n_frames * 513 * 4); hipMalloc(&dtab, tab.size() * 4);
+    hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    run<0>(fpw, "full kernel");
+    run<64>(fpw, "full kernel, vmcnt(0) at chunk top");
+    run<1>(fpw, "no global stores");
+    run<2>(fpw, "no E2 (register exchange)");
+    run<4>(fpw, "no E1 (LDS exchange)");
+    run<8>(fpw, "no DMA after first chunk");
+    run<16>(fpw, "no split strip");
+    run<32>(fpw, "no per-chunk wait+barrier (+races)");
+    run<8 | 32>(fpw, "no DMA, no barrier");
+    run<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier");
+    run<2 | 4 | 16>(fpw, "no exchanges at all");
+    run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)");
+    run<0>(fpw, "full kernel (again)");
+    run4<0>("full kernel");
+    run4<1>("no global stores");
+    run4<8>("no prefetch loads");
+    run4<1 | 8>("no stores, no loads");
+    run4<2>("no E2");
+    run4<4>("no E1");
+    run4<16>("no split strip");
+    run4<2 | 4 | 16>("no exchanges");
+    run4<1 | 2 | 4 | 8 | 16>("math only");
+    run4<0>("full kernel, 2 WG/CU", 2);
+    run4<0>("full kernel, 3 WG/CU", 3);
+    run4<0>("full kernel, 8 WG/CU (oversubscribed)", 8);
+    run4<0>("full kernel (again)");
+    return 0;
+}
