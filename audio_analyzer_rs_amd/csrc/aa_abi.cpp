@@ -367,7 +367,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             (aa::wave1024_variant() != 4 || cfg->hop % 2 == 0)) {
             // frames per workgroup: the tunable default, shrunk until the LDS need fits 64 KiB.
             const int variant = aa::wave1024_variant();
-            int fpw = variant == 3 ? 8 : 16;
+            int fpw = (variant == 3 || variant == 5) ? 8 : 16;
             if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))
                 fpw = std::atoi(s) > 0 ? std::atoi(s) : fpw;
             while (fpw > 1 && aa::wave1024_lds_dwords(fpw, cfg->hop, variant) > 16384)

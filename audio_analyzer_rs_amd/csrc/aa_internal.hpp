@@ -18,7 +18,8 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024XchDwords = 520;            // per-wave split exchange area
 // LDS dwords needed to stage `span` samples in the padded layout (+8 per 64).
 inline int wave1024_stage_dwords(int span) { return span + 8 * ((span + 63) / 64); }
-// Kernel variant: 4 (default) = barrier-free streaming, samples prefetched into VGPRs;
+// Kernel variant: 5 (default) = variant 3 with packed-f32 complex arithmetic;
+// 4 = barrier-free streaming, samples prefetched into VGPRs;
 // 3 = persistent, LDS-DMA double-buffered staging, first exchange
 // through LDS; 2 = one-shot workgroups, first exchange through LDS; 1 = one-shot, all-register
 // exchanges.  AA_W1024_VARIANT overrides (A/B runs only).
@@ -26,9 +27,9 @@ inline int wave1024_variant()
 {
     static const int v = [] {
         const char *s = std::getenv("AA_W1024_VARIANT");
-        if (s && s[0] >= '1' && s[0] <= '4')
+        if (s && s[0] >= '1' && s[0] <= '5')
             return s[0] - '0';
-        return 4;
+        return 5;
     }();
     return v;
 }
@@ -40,7 +41,7 @@ inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int variant)
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
     if (variant == 4)
         return 4 * kWave1024ScratchDwordsV3;                             // scratch only
-    if (variant == 3)
+    if (variant == 3 || variant == 5)
         return 2 * span + 4 * kWave1024ScratchDwordsV3;                  // double buffer, unpadded
     return span + 8 * ((span + 63) / 64) + 4 * (variant == 1 ? kWave1024XchDwords : kWave1024ScratchDwordsV2);
 }

@@ -125,6 +125,68 @@ __device__ __forceinline__ void dft8(float2 (&v)[8])
     v[3] = cadd(d2, d3); v[7] = csub(d2, d3);
 }
 
+// ---- packed-f32 complex arithmetic ------------------------------------------------
+// A complex value lives in an aligned VGPR pair (v2f) and is combined with v_pk_*_f32;
+// the rotations by -i / +i, conjugations and the complex multiply's swizzles ride on the
+// VOP3P op_sel / neg modifiers, so they cost no instruction.  hipcc emits v_xor/v_mov pairs
+// for those from vector code, hence the inline asm (pure register ops, no hazards of
+// their own; the asm is not volatile so the compiler schedules it freely).
+// Measured on gfx950 with 4 waves/SIMD: v_pk_add/mul/fma_f32 3.3 cycles for two lanes-ops
+// against 2.0-2.8 for one scalar op (profiles/r01_ubench_valu_gfx950.txt).
+__device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b)   // a + (-i) b = (a.x + b.y, a.y - b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_pi(v2f a, v2f b)   // a + (+i) b = (a.x - b.y, a.y + b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b)  // a + conj(b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)  // a - conj(b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)      // a * w
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));            // a * w.xx
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"     // + (-a.y, a.x) * w.yy
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// 8-point DFT over the register index on packed values (same radix-2 DIF flow as dft8).
+__device__ __forceinline__ void pk_dft8(v2f (&v)[8])
+{
+    const v2f hp = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f hn = {-0.70710678118654752440f, -0.70710678118654752440f};
+    v2f a0 = v[0] + v[4], b0 = v[0] - v[4];
+    v2f a1 = v[1] + v[5], b1 = v[1] - v[5];
+    v2f a2 = v[2] + v[6], b2 = v[2] - v[6];
+    v2f a3 = v[3] + v[7], b3 = v[3] - v[7];
+    b1 = pk_add_mi(b1, b1) * hp;                     // * W8^1 = (x+y, y-x) h
+    b3 = pk_add_pi(b3, b3) * hn;                     // * W8^3 = (y-x, -x-y) h
+    v2f c0 = a0 + a2, c2 = a0 - a2;
+    v2f c1 = a1 + a3, u = a1 - a3;                   // c3 = -i u
+    v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);   // b0 +- (-i b2)
+    v2f d1 = b1 + b3, w = b1 - b3;                   // d3 = -i w
+    v[0] = c0 + c1; v[4] = c0 - c1;
+    v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
+    v[1] = d0 + d1; v[5] = d0 - d1;
+    v[3] = pk_add_mi(d2, w); v[7] = pk_add_pi(d2, w);
+}
+
 // ---- cross-lane register transposes -----------------------------------------
 // "Swap bit p of the register index with bit q of the lane index" for an array of
 // 8 complex registers: for every pair (i, i|s), s = 1<<p, i&s == 0
@@ -227,6 +289,38 @@ __device__ __forceinline__ void exchange_high(float2 (&v)[8])
         xpose_pair_b5(v[i].x, v[i + 4].x);
         xpose_pair_b5(v[i].y, v[i + 4].y);
     }
+}
+
+// same exchange on packed values (vector elements are not addressable: go through floats)
+__device__ __forceinline__ void xpose_pk(v2f &a, v2f &b, int stage)
+{
+    float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    if (stage == 0) {
+        xpose_pair_b3(ax, bx);
+        xpose_pair_b3(ay, by);
+    } else if (stage == 1) {
+        xpose_pair_b4(ax, bx);
+        xpose_pair_b4(ay, by);
+    } else {
+        xpose_pair_b5(ax, bx);
+        xpose_pair_b5(ay, by);
+    }
+    a = v2f{ax, ay};
+    b = v2f{bx, by};
+}
+__device__ __forceinline__ void exchange_high(v2f (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i += 2)
+        xpose_pk(v[i], v[i + 1], 0);
+#pragma unroll
+    for (int g = 0; g < 8; g += 4)
+#pragma unroll
+        for (int i = g; i < g + 2; ++i)
+            xpose_pk(v[i], v[i + 2], 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        xpose_pk(v[i], v[i + 4], 2);
 }
 
 // ------------------------------------------------ wave-per-frame, n_fft = 1024 --
@@ -745,6 +839,210 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v3_kernel(
     AA_STAMP_DUMP(dbg)
 }
 
+// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 5 --
+// Variant 3 (persistent, LDS-DMA double buffer, E1 through LDS, aligned nontemporal row
+// stores) with every complex operation on packed f32 (pk_* helpers above).  Occupancy
+// sweeps of the ablated kernel showed the compute side saturating the VALU (~2.8 cycles
+// per scalar op in situ): packing halves the instruction count of the butterflies,
+// twiddles and the split.
+template <int OUT, int ABL = 0, bool WIDE = false>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
+    float log_floor)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
+    const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
+    const int max_span = (frames_per_wg - 1) * hop + 1024;
+    v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kW1024ScratchDwordsV3);
+
+    auto stage = [&](int64_t c, int which) {
+        const int64_t f0 = c * frames_per_wg;
+        const int64_t left = n_frames - f0;
+        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+        const int span4 = ((nf - 1) * hop + 1024) >> 2;
+        const float *src = x + (frame_begin + f0) * (int64_t)hop;
+        float *dst = smem + which * max_span;
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+            const int q = qb + lane;
+            if (q < span4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + 4 * (int64_t)q),
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+        }
+    };
+
+    if (c0 < c1)
+        stage(c0, 0);
+
+    // per-lane constants as packed pairs
+    v2f win[8], twA[8], twB[8], tws[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = v2f{tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]};
+        twB[k] = v2f{tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        tws[j] = v2f{tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]};
+
+    const unsigned smem_addr = lds_addr(smem);
+    v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
+    const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    constexpr int NB = 513;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+
+    for (int64_t c = c0; c < c1; ++c) {
+        const int cur = (int)(c - c0) & 1;
+        if ((ABL & 64) || c == c0 || frames_per_wg != 8)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < c1 && !(ABL & 8))
+            stage(c + 1, cur ^ 1);
+
+        const int64_t f0 = c * frames_per_wg;
+        const int64_t left = n_frames - f0;
+        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
+
+        for (int t = wave; t < nf; t += 4) {
+            const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
+            v2f v[8];
+            {
+                v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<512>(fr), s2 = lds_read_b64<1024>(fr),
+                    s3 = lds_read_b64<1536>(fr), s4 = lds_read_b64<2048>(fr), s5 = lds_read_b64<2560>(fr),
+                    s6 = lds_read_b64<3072>(fr), s7 = lds_read_b64<3584>(fr);
+                lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
+                v[0] = s0 * win[0]; v[1] = s1 * win[1]; v[2] = s2 * win[2]; v[3] = s3 * win[3];
+                v[4] = s4 * win[4]; v[5] = s5 * win[5]; v[6] = s6 * win[6]; v[7] = s7 * win[7];
+            }
+            pk_dft8(v);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                v[k] = pk_cmul(v[k], twA[k]);
+            // ---- E1 through LDS ----
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    e1_wr[8 * k] = v[k];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v4f qv = e1_rd[i];
+                    v[2 * i] = v2f{qv.x, qv.y};
+                    v[2 * i + 1] = v2f{qv.z, qv.w};
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            pk_dft8(v);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                v[k] = pk_cmul(v[k], twB[k]);
+            if (!(ABL & 2)) {
+                // the DPP / permlane moves read registers the packed asm just wrote: keep the
+                // two wait states the hazard rules ask for (the compiler cannot see into asm)
+                asm volatile("s_nop 1");
+                exchange_high(v);
+            }
+            pk_dft8(v);
+
+            // ---- split ----
+            v2f prt[4];
+            if (!(ABL & 16)) {
+#pragma unroll
+                for (int j = 4; j < 8; ++j)
+                    scr[lane + 64 * (j - 4)] = v[j];
+                if (lane == 0)
+                    scr[256] = v[0];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    prt[j] = scr[256 - (lane + 64 * j)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    prt[j] = v[7 - j];
+            }
+            float *row = out + (f0 + t) * (int64_t)COLS;
+            v2f xk[4], xm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v2f e = pk_add_conj(v[j], prt[j]), o = pk_sub_conj(v[j], prt[j]);
+                v2f tt = pk_cmul(o, tws[j]);
+                xk[j] = e + tt;
+                xm[j] = e - tt;                                  // X[512-k] = conj(xm)
+            }
+            if (OUT == kComplex) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = lane + 64 * j;
+                    reinterpret_cast<v2f *>(row)[k] = xk[j];
+                    reinterpret_cast<v2f *>(row)[512 - k] = v2f{xm[j].x, -xm[j].y};
+                }
+                if (lane == 0)
+                    reinterpret_cast<v2f *>(row)[256] = v2f{2.0f * v[4].x, -2.0f * v[4].y};
+            } else {
+                float mk[4], mm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
+                    mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+                }
+                const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+                if (ABL & 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("" ::"v"(mk[j]), "v"(mm[j]));
+                } else if (WIDE) {
+                    // aligned nontemporal row stores through LDS (see variant 3)
+                    const int sh = (int)((f0 + t) & 3);
+                    float *lrow = reinterpret_cast<float *>(scr) + sh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        lrow[lane + 64 * j] = mk[j];
+                        lrow[512 - lane - 64 * j] = mm[j];
+                    }
+                    if (lane == 0)
+                        lrow[256] = m256;
+                    __builtin_amdgcn_wave_barrier();
+                    const float *lw = reinterpret_cast<const float *>(scr);
+                    float *gw = row - sh;
+                    v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                    __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                    if (lane < 63) {
+                        v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * lane);
+                        __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                    }
+                    const int hi = lane < 4 ? lane : 508 + lane;
+                    const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
+                    if (ok)
+                        gw[hi] = lw[hi];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        row[lane + 64 * j] = mk[j];
+                        row[512 - lane - 64 * j] = mm[j];
+                    }
+                    if (lane == 0)
+                        row[256] = m256;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------ wave-per-frame, n_fft = 1024, variant 4 --
 // Barrier-free streaming form: every wave is independent.  A workgroup (4 waves) owns a
 // contiguous run of frames and wave w takes frames run_begin + 4 i + w, so the four waves
@@ -1167,7 +1465,15 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
             cached_lds = lds;                                                                  \
         }                                                                                      \
         int64_t g = cached_grid < chunks ? cached_grid : chunks;                               \
-        if (wide)                                                                              \
+        if (variant == 5 && wide)                                                              \
+            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, true>), dim3((unsigned)g), block,    \
+                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
+                               frames_per_wg, chunks, log_floor);                              \
+        else if (variant == 5)                                                                 \
+            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, false>), dim3((unsigned)g), block,   \
+                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
+                               frames_per_wg, chunks, log_floor);                              \
+        else if (wide)                                                                         \
             hipLaunchKernelGGL((stft_wave1024_v3_kernel<K, 0, true>), dim3((unsigned)g), block,    \
                                lds, stream, x, out, table, frame_begin, n_frames, hop,         \
                                frames_per_wg, chunks, log_floor);                              \

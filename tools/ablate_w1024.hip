@@ -12,12 +12,13 @@ static const int hop = 256;
 static const int64_t n_samples = 28800000, n_frames = (n_samples - 1024) / hop + 1;
 
 template <int ABL>
-double run(int fpw, const char *name)
+double run(int fpw, const char *name, int force_per_cu = 0)
 {
     const int64_t chunks = (n_frames + fpw - 1) / fpw;
     const size_t lds = aa::wave1024_lds_bytes(fpw, hop, 3);
     int per_cu = 1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v3_kernel<aa::kMag, ABL>, 256, lds);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v5_kernel<aa::kMag, ABL, true>, 256, lds);
+    if (force_per_cu) per_cu = force_per_cu;
     int grid = 256 * per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -25,7 +26,7 @@ double run(int fpw, const char *name)
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL((aa::stft_wave1024_v3_kernel<aa::kMag, ABL>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+            hipLaunchKernelGGL((aa::stft_wave1024_v5_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
                                (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
@@ -101,8 +102,9 @@ int main(int argc, char **argv)
     hipMalloc(&dx, n_samples * 4); hipMalloc(&dout, n_frames * 513 * 4); hipMalloc(&dtab, tab.size() * 4);
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
-    run<0>(fpw, "full kernel");
-    run<64>(fpw, "full kernel, vmcnt(0) at chunk top");
+    for (int pc : {2, 4, 5}) run<0>(fpw, "full kernel", pc);
+    for (int pc : {2, 4, 5}) run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only", pc);
+    for (int pc : {2, 4, 5}) run<1 | 8 | 32>(fpw, "no stores/DMA/barrier", pc);
     run<1>(fpw, "no global stores");
     run<2>(fpw, "no E2 (register exchange)");
     run<4>(fpw, "no E1 (LDS exchange)");
@@ -110,22 +112,7 @@ int main(int argc, char **argv)
     run<16>(fpw, "no split strip");
     run<32>(fpw, "no per-chunk wait+barrier (+races)");
     run<8 | 32>(fpw, "no DMA, no barrier");
-    run<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier");
     run<2 | 4 | 16>(fpw, "no exchanges at all");
-    run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)");
     run<0>(fpw, "full kernel (again)");
-    run4<0>("full kernel");
-    run4<1>("no global stores");
-    run4<8>("no prefetch loads");
-    run4<1 | 8>("no stores, no loads");
-    run4<2>("no E2");
-    run4<4>("no E1");
-    run4<16>("no split strip");
-    run4<2 | 4 | 16>("no exchanges");
-    run4<1 | 2 | 4 | 8 | 16>("math only");
-    run4<0>("full kernel, 2 WG/CU", 2);
-    run4<0>("full kernel, 3 WG/CU", 3);
-    run4<0>("full kernel, 8 WG/CU (oversubscribed)", 8);
-    run4<0>("full kernel (again)");
     return 0;
 }
