@@ -113,18 +113,16 @@ void hann_f32(int n, float *w)
 }
 
 // Per-lane constants of the wave-per-frame 1024 kernel, [kWave1024Rows][64]:
-//   rows  0..15  0.5 * w[2*(64 j + n2) + c]           (row 2j + c),  n2 = pass-A point of the lane
-//   rows 16..29  W_512^(n2 k)  re,im   k = 1..7        (pass A twiddles)
+//   rows  0..15  0.5 * w[2*(64 j + lane) + c]         (row 2j + c)
+//   rows 16..29  W_512^(lane k)  re,im   k = 1..7      (pass A twiddles)
 //   rows 30..43  W_64^(b k)    re,im   k = 1..7, b = lane>>3   (pass B twiddles)
 //   rows 44..51  (-sin t, -cos t), t = 2 pi (lane + 64 j)/1024, j = 0..3   (= -i W_1024^k)
-void build_wave1024_table(const float *window, bool natural, std::vector<float> *tab)
+void build_wave1024_table(const float *window, std::vector<float> *tab)
 {
     tab->assign((size_t)aa::kWave1024Rows * 64, 0.0f);
     float *T = tab->data();
     for (int lane = 0; lane < 64; ++lane) {
-        // pass-A point index of the lane: variant 3 reads m = 64 j + lane, variants 1/2
-        // m = 64 j + 8*(lane&7) + (lane>>3)
-        const int n2 = natural ? lane : 8 * (lane & 7) + (lane >> 3);
+        const int n2 = lane;   // pass A reads complex point m = 64 j + lane
         const int b = lane >> 3;
         for (int j = 0; j < 8; ++j)
             for (int c = 0; c < 2; ++c)
@@ -166,7 +164,7 @@ struct aa_stft_plan {
     FftTables tabs;
     // wave1024 path
     bool wave1024 = false;
-    int frames_per_wg = 16;
+    int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
     // host-execute workspace
     float *d_ws_in = nullptr;
@@ -363,18 +361,16 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
         int r = build_fft_tables(cfg->n_fft, &p->tabs);
         if (r != AA_OK)
             return r;
-        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0 &&
-            (aa::wave1024_variant() != 4 || cfg->hop % 2 == 0)) {
-            // frames per workgroup: the tunable default, shrunk until the LDS need fits 64 KiB.
-            const int variant = aa::wave1024_variant();
-            int fpw = (variant == 3 || variant == 5) ? 8 : 16;
+        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
+            // frames per workgroup chunk: the tunable default, shrunk until the LDS need fits 64 KiB.
+            int fpw = 8;
             if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))
                 fpw = std::atoi(s) > 0 ? std::atoi(s) : fpw;
-            while (fpw > 1 && aa::wave1024_lds_dwords(fpw, cfg->hop, variant) > 16384)
+            while (fpw > 1 && aa::wave1024_lds_dwords(fpw, cfg->hop) > 16384)
                 --fpw;
-            if (aa::wave1024_lds_dwords(fpw, cfg->hop, variant) <= 16384) {
+            if (aa::wave1024_lds_dwords(fpw, cfg->hop) <= 16384) {
                 std::vector<float> tab;
-                build_wave1024_table(p->window_host.data(), variant >= 3, &tab);
+                build_wave1024_table(p->window_host.data(), &tab);
                 AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
                                  hipMemcpyHostToDevice));

@@ -15,39 +15,27 @@ enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3 };
 // build_wave1024_table in aa_abi.cpp for the row meaning).
 constexpr int kWave1024Rows = 52;
 constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
-constexpr int kWave1024XchDwords = 520;            // per-wave split exchange area
-// LDS dwords needed to stage `span` samples in the padded layout (+8 per 64).
-inline int wave1024_stage_dwords(int span) { return span + 8 * ((span + 63) / 64); }
-// Kernel variant: 5 (default) = variant 3 with packed-f32 complex arithmetic;
-// 4 = barrier-free streaming, samples prefetched into VGPRs;
-// 3 = persistent, LDS-DMA double-buffered staging, first exchange
-// through LDS; 2 = one-shot workgroups, first exchange through LDS; 1 = one-shot, all-register
-// exchanges.  AA_W1024_VARIANT overrides (A/B runs only).
+constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
+// Kernel variant: 5 (default) = packed-f32 complex arithmetic; 3 = its scalar twin.
+// AA_W1024_VARIANT=3 overrides (A/B runs only).
 inline int wave1024_variant()
 {
     static const int v = [] {
         const char *s = std::getenv("AA_W1024_VARIANT");
-        if (s && s[0] >= '1' && s[0] <= '5')
-            return s[0] - '0';
-        return 5;
+        return (s && s[0] == '3') ? 3 : 5;
     }();
     return v;
 }
-constexpr int kWave1024ScratchDwordsV2 = 1152;     // per-wave E1 scratch / split strip (v2)
-constexpr int kWave1024ScratchDwordsV3 = 1056;     // same, natural lane mapping (v3)
-// LDS dwords a workgroup needs for `frames_per_wg` frames.
-inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int variant)
+// LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
+// of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
+inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
-    if (variant == 4)
-        return 4 * kWave1024ScratchDwordsV3;                             // scratch only
-    if (variant == 3 || variant == 5)
-        return 2 * span + 4 * kWave1024ScratchDwordsV3;                  // double buffer, unpadded
-    return span + 8 * ((span + 63) / 64) + 4 * (variant == 1 ? kWave1024XchDwords : kWave1024ScratchDwordsV2);
+    return 2 * span + 4 * kWave1024ScratchDwords;
 }
-inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int variant)
+inline size_t wave1024_lds_bytes(int frames_per_wg, int hop)
 {
-    return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop, variant);
+    return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop);
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,

@@ -201,27 +201,6 @@ __device__ __forceinline__ float dpp_update(float old, float src)
                                                       CTRL, 0xF, BANK_MASK, false));
 }
 
-// quad stages (lane bit 0 or 1): permute everything, then select on the lane bit.
-template <int QUAD_PERM>
-__device__ __forceinline__ void xpose_pair_quad(float &ri, float &rj, bool lane_bit)
-{
-    float ti = dpp_update<QUAD_PERM, 0xF>(ri, ri);   // partner's r[i]
-    float tj = dpp_update<QUAD_PERM, 0xF>(rj, rj);   // partner's r[i|s]
-    float ni = lane_bit ? tj : ri;
-    float nj = lane_bit ? rj : ti;
-    ri = ni;
-    rj = nj;
-}
-
-// lane bit 2: row_shr:4 into banks 1,3 ; row_shl:4 into banks 0,2 (bank = 4 lanes).
-__device__ __forceinline__ void xpose_pair_b2(float &ri, float &rj)
-{
-    float ni = dpp_update<0x114, 0xA>(ri, rj);   // lanes 4-7,12-15 read lane-4's r[i|s]
-    float nj = dpp_update<0x104, 0x5>(rj, ri);   // lanes 0-3,8-11  read lane+4's r[i]
-    ri = ni;
-    rj = nj;
-}
-
 // lane bit 3: row_ror:8 (a rotation by half a row is its own inverse).
 __device__ __forceinline__ void xpose_pair_b3(float &ri, float &rj)
 {
@@ -244,29 +223,6 @@ __device__ __forceinline__ void xpose_pair_b5(float &ri, float &rj)
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ri), __float_as_uint(rj), false, false);
     ri = __uint_as_float(r[0]);
     rj = __uint_as_float(r[1]);
-}
-
-// register bits 0,1,2 <-> lane bits 0,1,2
-__device__ __forceinline__ void exchange_low(float2 (&v)[8], int lane)
-{
-    const bool l0 = lane & 1, l1 = lane & 2;
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {   // p = 0 : pairs (i, i+1)
-        xpose_pair_quad<0xB1>(v[i].x, v[i + 1].x, l0);
-        xpose_pair_quad<0xB1>(v[i].y, v[i + 1].y, l0);
-    }
-#pragma unroll
-    for (int g = 0; g < 8; g += 4)     // p = 1 : pairs (i, i+2)
-#pragma unroll
-        for (int i = g; i < g + 2; ++i) {
-            xpose_pair_quad<0x4E>(v[i].x, v[i + 2].x, l1);
-            xpose_pair_quad<0x4E>(v[i].y, v[i + 2].y, l1);
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {      // p = 2 : pairs (i, i+4)
-        xpose_pair_b2(v[i].x, v[i + 4].x);
-        xpose_pair_b2(v[i].y, v[i + 4].y);
-    }
 }
 
 // register bits 0,1,2 <-> lane bits 3,4,5
@@ -323,279 +279,9 @@ __device__ __forceinline__ void exchange_high(v2f (&v)[8])
         xpose_pk(v[i], v[i + 4], 2);
 }
 
-// ------------------------------------------------ wave-per-frame, n_fft = 1024 --
-// One wavefront transforms one frame: the 1024 windowed reals are read as 512
-// complex points z[m] (8 per lane), 512 = 8 x 8 x 8:
-//   pass A  radix-8 over j      (m = 64 j + n2, n2 = 8a + b; lane = a + 8b), twiddle W_512^(n2 k1)
-//   E1      registers <-> lane bits 0-2 (DPP)                    -> lane = k1 + 8b, regs a
-//   pass B  radix-8 over a, twiddle W_64^(b ka)
-//   E2      registers <-> lane bits 3-5 (DPP row_ror + permlane swaps) -> lane = k1 + 8 ka, regs b
-//   pass C  radix-8 over b      -> lane L holds Z[L + 64 kb], kb = 0..7
-//   split   X[k], X[512-k] from Z[k], Z[512-k]; the partner half travels through a
-//           wave-private LDS strip (4 ds_write_b64 + 4 ds_read_b64 per lane).
-// A workgroup (4 waves) stages the samples of `frames_per_wg` consecutive frames in
-// LDS once (each sample is used by n_fft/hop frames), padded by 8 dwords per 64 so
-// that the lane = a + 8b read pattern is bank-conflict free for ds_read_b64.
-// The window table carries a factor 0.5 (exact) so the split needs no halving.
-template <int OUT>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
-    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
-    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, float log_floor)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // XCD-aware chunk id: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so
-    // give each XCD a contiguous run of chunks - neighbouring chunks share their halo
-    // (n_fft - hop samples) through that XCD's L2.  Bijective for any grid size.
-    const int nwg = gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-
-    const int64_t f0 = (int64_t)chunk * frames_per_wg;
-    const int64_t left = n_frames - f0;
-    const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
-    const float *src = x + (frame_begin + f0) * (int64_t)hop;
-    const int span4 = ((nf - 1) * hop + 1024) >> 2;
-    const int max_span = (frames_per_wg - 1) * hop + 1024;
-    float *xch = smem + (max_span + 8 * ((max_span + 63) >> 6)) + wave * kWave1024XchDwords;
-
-    // stage: float4 q -> dword 4q + 8*(q>>4)
-    for (int q = tid; q < span4; q += kWave1024Threads) {
-        float4 s = reinterpret_cast<const float4 *>(src)[q];
-        *reinterpret_cast<float4 *>(&smem[4 * q + 8 * (q >> 4)]) = s;
-    }
-
-    // per-lane constants (table rows are lane-contiguous)
-    float win[16];
-    float2 twA[8], twB[8], tws[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        win[i] = tab[i * 64 + lane];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
-        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
-
-    const int n2 = 8 * (lane & 7) + (lane >> 3);
-    const int lane_off = 2 * n2 + 8 * (n2 >> 5);
-    constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
-
-    __syncthreads();
-
-    for (int t = wave; t < nf; t += 4) {
-        const int fb = t * hop;                       // multiple of 64
-        const float *fr = smem + fb + (fb >> 3) + lane_off;
-        float2 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float2 s = *reinterpret_cast<const float2 *>(fr + 144 * j);
-            v[j] = make_float2(s.x * win[2 * j], s.y * win[2 * j + 1]);
-        }
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twA[k]);
-        exchange_low(v, lane);
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twB[k]);
-        exchange_high(v);
-        dft8(v);
-
-        // ---- split: partner half through the wave-private LDS strip --------------
-        // strip[c] (complex) holds Z[256 + c], c = 0..255, and strip[256] = Z[512] := Z[0]
-        float2 *strip = reinterpret_cast<float2 *>(xch);
-#pragma unroll
-        for (int j = 4; j < 8; ++j)
-            strip[lane + 64 * (j - 4)] = v[j];
-        if (lane == 0)
-            strip[256] = v[0];
-        __builtin_amdgcn_wave_barrier();
-        float *row = out + (f0 + t) * (int64_t)COLS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = lane + 64 * j;
-            float2 a = v[j];
-            float2 p = strip[256 - k];
-            float2 bc = make_float2(p.x, -p.y);
-            float2 e = cadd(a, bc), o = csub(a, bc);
-            float2 tt = cmul(o, tws[j]);
-            float2 xk = cadd(e, tt);
-            float2 xm = csub(e, tt);                  // X[512-k] = conj(xm)
-            if (OUT == kComplex) {
-                reinterpret_cast<float2 *>(row)[k] = xk;
-                reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
-            } else {
-                row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
-                row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
-            }
-        }
-        if (lane == 0) {                              // k = 256 pairs with itself
-            float2 z = v[4];
-            if (OUT == kComplex)
-                reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
-            else
-                row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 2 --
-// Same decomposition as stft_wave1024_kernel, but the first exchange (registers <-> lane
-// bits 0-2) goes through a wave-private LDS scratch instead of DPP + select: measured on
-// gfx950 (profiles/r01_ubench_valu_gfx950.txt) v_cndmask_b32 costs 12-19 cycles and a DPP
-// move 3-4, while the LDS pipe sat at 16 % — the kernel was VALU-bound on data movement.
-//   write  lane (a,b) stores Y[k1] at complex address 72 b + 8 k1 + a        (ds_write_b64,
-//          16 consecutive lanes cover 32 banks -> conflict free)
-//   read   lane (k1,b) loads a = 0..7 from 72 b + 8 k1 + a as 4 x ds_read_b128; the skew
-//          72 = 64 + 8 makes the sixteen 16-byte slots of every b128 lane group distinct.
-// The same scratch is reused as the split strip.  The second exchange (lane bits 3-5) stays
-// in registers: row_ror:8 DPP moves with bank masks and v_permlane{16,32}_swap need no select.
-constexpr int kW1024ScratchDwords = 1152;   // 568 complex, rounded up
-
-template <int OUT>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v2_kernel(
-    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
-    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, float log_floor)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    const int nwg = gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-
-    const int64_t f0 = (int64_t)chunk * frames_per_wg;
-    const int64_t left = n_frames - f0;
-    const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
-    const float *src = x + (frame_begin + f0) * (int64_t)hop;
-    const int span4 = ((nf - 1) * hop + 1024) >> 2;
-    const int max_span = (frames_per_wg - 1) * hop + 1024;
-    float2 *scr = reinterpret_cast<float2 *>(smem + (max_span + 8 * ((max_span + 63) >> 6)) +
-                                             wave * kW1024ScratchDwords);
-
-    for (int q = tid; q < span4; q += kWave1024Threads) {
-        float4 s = reinterpret_cast<const float4 *>(src)[q];
-        *reinterpret_cast<float4 *>(&smem[4 * q + 8 * (q >> 4)]) = s;
-    }
-
-    float win[16];
-    float2 twA[8], twB[8], tws[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        win[i] = tab[i * 64 + lane];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
-        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
-
-    const int la = lane & 7, lb = lane >> 3;
-    const int n2 = 8 * la + lb;
-    const int lane_off = 2 * n2 + 8 * (n2 >> 5);
-    const unsigned smem_addr = lds_addr(smem);
-    float2 *e1_wr = scr + 72 * lb + la;                                     // + 8 k1
-    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 72 * lb + 8 * la);
-    constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
-
-    __syncthreads();
-
-    for (int t = wave; t < nf; t += 4) {
-        const int fb = t * hop;
-        const unsigned fr = smem_addr + 4u * (unsigned)(fb + (fb >> 3) + lane_off);
-        float2 v[8];
-        {
-            v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<576>(fr), s2 = lds_read_b64<1152>(fr),
-                s3 = lds_read_b64<1728>(fr), s4 = lds_read_b64<2304>(fr), s5 = lds_read_b64<2880>(fr),
-                s6 = lds_read_b64<3456>(fr), s7 = lds_read_b64<4032>(fr);
-            lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
-            v[0] = make_float2(s0.x * win[0], s0.y * win[1]);
-            v[1] = make_float2(s1.x * win[2], s1.y * win[3]);
-            v[2] = make_float2(s2.x * win[4], s2.y * win[5]);
-            v[3] = make_float2(s3.x * win[6], s3.y * win[7]);
-            v[4] = make_float2(s4.x * win[8], s4.y * win[9]);
-            v[5] = make_float2(s5.x * win[10], s5.y * win[11]);
-            v[6] = make_float2(s6.x * win[12], s6.y * win[13]);
-            v[7] = make_float2(s7.x * win[14], s7.y * win[15]);
-        }
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twA[k]);
-        // ---- E1 through LDS ----
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            e1_wr[8 * k] = v[k];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 qv = e1_rd[i];
-            v[2 * i] = make_float2(qv.x, qv.y);
-            v[2 * i + 1] = make_float2(qv.z, qv.w);
-        }
-        __builtin_amdgcn_wave_barrier();
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twB[k]);
-        exchange_high(v);
-        dft8(v);
-
-        // ---- split ----
-#pragma unroll
-        for (int j = 4; j < 8; ++j)
-            scr[lane + 64 * (j - 4)] = v[j];
-        if (lane == 0)
-            scr[256] = v[0];
-        __builtin_amdgcn_wave_barrier();
-        float *row = out + (f0 + t) * (int64_t)COLS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = lane + 64 * j;
-            float2 a = v[j];
-            float2 p = scr[256 - k];
-            float2 bc = make_float2(p.x, -p.y);
-            float2 e = cadd(a, bc), o = csub(a, bc);
-            float2 tt = cmul(o, tws[j]);
-            float2 xk = cadd(e, tt);
-            float2 xm = csub(e, tt);
-            if (OUT == kComplex) {
-                reinterpret_cast<float2 *>(row)[k] = xk;
-                reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
-            } else {
-                row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
-                row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
-            }
-        }
-        if (lane == 0) {
-            float2 z = v[4];
-            if (OUT == kComplex)
-                reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
-            else
-                row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ------------------------------------------ wave-per-frame, n_fft = 1024, variant 3 --
-// Persistent, software-pipelined form of variant 2 (the shipped default):
+// Persistent, software-pipelined kernel with scalar f32 arithmetic (the packed variant 5
+// below is the shipped default; this one is its A/B twin, AA_W1024_VARIANT=3):
 //   * a workgroup owns a contiguous run of chunks (frames_per_wg frames each) and loops
 //     over them; the per-lane constant table is loaded once per workgroup, not per chunk;
 //   * the samples of chunk c+1 are fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
@@ -605,7 +291,6 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v2_kernel(
 //   * E1 scratch addressing for that mapping: writer lane (a = l>>3, b = l&7) stores Y[k1]
 //     at complex 66 b + 8 k1 + a, reader lane (k1 = L&7, b = L>>3) loads 8 consecutive
 //     complex from 66 b + 8 k1 (4 x ds_read_b128); both sides are bank-conflict free.
-constexpr int kW1024ScratchDwordsV3 = 1056;   // 526 complex, rounded up to 16 B
 
 // ABL: ablation mask for tools/ablate_w1024.hip (diagnostic; 0 in the shipped library):
 //   1 no global stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split strip,
@@ -628,7 +313,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v3_kernel(
     const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
     const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
     const int max_span = (frames_per_wg - 1) * hop + 1024;          // floats, multiple of 64
-    float2 *scr = reinterpret_cast<float2 *>(smem + 2 * max_span + wave * kW1024ScratchDwordsV3);
+    float2 *scr = reinterpret_cast<float2 *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
 
     // LDS-DMA of one chunk's samples into buffer `which` (wave w moves 1 KiB pieces w, w+4, ..)
     auto stage = [&](int64_t c, int which) {
@@ -855,11 +540,12 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    AA_CLK_BEGIN
 
     const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
     const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
     const int max_span = (frames_per_wg - 1) * hop + 1024;
-    v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kW1024ScratchDwordsV3);
+    v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
 
     auto stage = [&](int64_t c, int which) {
         const int64_t f0 = c * frames_per_wg;
@@ -1040,173 +726,6 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-    }
-}
-
-// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 4 --
-// Barrier-free streaming form: every wave is independent.  A workgroup (4 waves) owns a
-// contiguous run of frames and wave w takes frames run_begin + 4 i + w, so the four waves
-// read overlapping samples at about the same time (served by L1/L2; HBM sees each sample
-// once) — no LDS staging, no DMA, no __syncthreads.  The samples of the wave's NEXT frame
-// are prefetched straight into VGPRs (8 x global_load_dwordx2, 512 B per instruction,
-// m = 64 j + lane) before the current frame is transformed; the compiler's counted vmcnt
-// lets the 9 row stores of the previous frame stay in flight.  LDS holds only the
-// wave-private E1 / split scratch.  Ablation on gfx950 (tools/ablate_w1024.hip) showed the
-// LDS-DMA + barrier structure of variant 3 serialising memory phases against compute.
-template <int OUT, int ABL = 0>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v4_kernel(
-    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
-    int64_t frame_begin, int64_t n_frames, int hop, float log_floor)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    AA_CLK_BEGIN
-
-    // frames [r0, r1) of this workgroup; wave w: r0 + w, r0 + w + 4, ...
-    const int64_t r0 = (int64_t)blockIdx.x * n_frames / gridDim.x;
-    const int64_t r1 = (int64_t)(blockIdx.x + 1) * n_frames / gridDim.x;
-    float2 *scr = reinterpret_cast<float2 *>(smem + wave * kW1024ScratchDwordsV3);
-
-    float win[16];
-    float2 twA[8], twB[8], tws[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        win[i] = tab[i * 64 + lane];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
-        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
-
-    float2 *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
-    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
-
-    int64_t t = r0 + wave;
-    if (t >= r1)
-        return;
-    const float2 *src = reinterpret_cast<const float2 *>(x + (frame_begin + t) * (int64_t)hop) + lane;
-    const int64_t src_step = 2 * (int64_t)hop;          // float2 units per 4 frames
-
-    // one frame: windowed samples in `v` -> row t of the output
-    auto transform = [&](float2 (&v)[8], int64_t tt) {
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twA[k]);
-        // ---- E1 through LDS ----
-        if (!(ABL & 4)) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                e1_wr[8 * k] = v[k];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 qv = e1_rd[i];
-                v[2 * i] = make_float2(qv.x, qv.y);
-                v[2 * i + 1] = make_float2(qv.z, qv.w);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        dft8(v);
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            v[k] = cmul(v[k], twB[k]);
-        if (!(ABL & 2))
-            exchange_high(v);
-        dft8(v);
-
-        // ---- split ----
-        float2 prt[4];
-        if (!(ABL & 16)) {
-#pragma unroll
-            for (int j = 4; j < 8; ++j)
-                scr[lane + 64 * (j - 4)] = v[j];
-            if (lane == 0)
-                scr[256] = v[0];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                prt[j] = scr[256 - (lane + 64 * j)];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                prt[j] = v[7 - j];
-        }
-        float *row = out + tt * (int64_t)COLS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = lane + 64 * j;
-            float2 a = v[j];
-            float2 p = prt[j];
-            float2 bc = make_float2(p.x, -p.y);
-            float2 e = cadd(a, bc), o = csub(a, bc);
-            float2 tt2 = cmul(o, tws[j]);
-            float2 xk = cadd(e, tt2);
-            float2 xm = csub(e, tt2);
-            if (ABL & 1) {
-                float q0 = bin_value<OUT>(xk.x, xk.y, log_floor), q1 = bin_value<OUT>(xm.x, xm.y, log_floor);
-                asm volatile("" ::"v"(q0), "v"(q1));
-            } else if (OUT == kComplex) {
-                reinterpret_cast<float2 *>(row)[k] = xk;
-                reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
-            } else {
-                row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
-                row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
-            }
-        }
-        if (lane == 0 && !(ABL & 1)) {
-            float2 z = v[4];
-            if (OUT == kComplex)
-                reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
-            else
-                row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // Prefetch distance 2: vmcnt completes in issue order and counts stores, so a load only
-    // returns after every older store of the wave has been acknowledged; keeping the awaited
-    // loads two frames older than the newest stores takes the store latency off the path.
-    float2 bufA[8], bufB[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        bufA[j] = src[64 * j];
-    if (t + 4 < r1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            bufB[j] = src[src_step + 64 * j];
-    }
-    src += 2 * src_step;
-    for (; t < r1; t += 8) {
-        float2 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[j] = make_float2(bufA[j].x * win[2 * j], bufA[j].y * win[2 * j + 1]);
-        if (t + 8 < r1 && !(ABL & 8)) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                bufA[j] = src[64 * j];
-        }
-        transform(v, t);
-        if (t + 4 >= r1)
-            break;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[j] = make_float2(bufB[j].x * win[2 * j], bufB[j].y * win[2 * j + 1]);
-        if (t + 12 < r1 && !(ABL & 8)) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                bufB[j] = src[src_step + 64 * j];
-        }
-        transform(v, t + 4);
-        src += 2 * src_step;
     }
     AA_CLK_END
 }
@@ -1415,9 +934,10 @@ __global__ void irfft_kernel(const float *__restrict__ spec, float *__restrict__
 
 // ------------------------------------------------------------------- launchers --
 #if !defined(AA_STAMPS) && !defined(AA_ABLATE)   // diagnostic builds drive the kernels themselves
-// Persistent grid for variant 3: resident workgroups per CU (occupancy API) x CUs.
+// Persistent grid: resident workgroups per CU (occupancy API) x CUs.  There is no
+// inter-workgroup dependency, so an over- or under-estimate only changes speed.
 template <typename K>
-static int persistent_grid(K kernel, size_t lds, int64_t n_chunks)
+static int persistent_grid(K kernel, size_t lds)
 {
     int dev = 0, cus = 256, per_cu = 1;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -1428,8 +948,39 @@ static int persistent_grid(K kernel, size_t lds, int64_t n_chunks)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave1024Threads, lds) != hipSuccess ||
         per_cu < 1)
         per_cu = 1;
-    int64_t g = (int64_t)cus * per_cu;
-    return (int)(g < n_chunks ? g : n_chunks);
+    return cus * per_cu;
+}
+
+template <int K>
+static hipError_t launch_wave1024_kind(bool packed, bool wide, const float *x, float *out,
+                                       const float *table, int64_t frame_begin, int64_t n_frames,
+                                       int hop, int frames_per_wg, float log_floor, hipStream_t stream)
+{
+    const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop);
+    static int cached_grid[2] = {0, 0};
+    static size_t cached_lds[2] = {0, 0};
+    const int slot = packed ? 1 : 0;
+    if (cached_grid[slot] == 0 || cached_lds[slot] != lds) {
+        cached_grid[slot] = packed ? persistent_grid(stft_wave1024_v5_kernel<K, 0, true>, lds)
+                                   : persistent_grid(stft_wave1024_v3_kernel<K, 0, true>, lds);
+        cached_lds[slot] = lds;
+    }
+    const dim3 grid((unsigned)(cached_grid[slot] < chunks ? cached_grid[slot] : chunks));
+    const dim3 block(kWave1024Threads);
+#define AA_GO(KERNEL, W)                                                                       \
+    hipLaunchKernelGGL((KERNEL<K, 0, W>), grid, block, lds, stream, x, out, table, frame_begin, \
+                       n_frames, hop, frames_per_wg, chunks, log_floor)
+    if (packed && wide)
+        AA_GO(stft_wave1024_v5_kernel, true);
+    else if (packed)
+        AA_GO(stft_wave1024_v5_kernel, false);
+    else if (wide)
+        AA_GO(stft_wave1024_v3_kernel, true);
+    else
+        AA_GO(stft_wave1024_v3_kernel, false);
+#undef AA_GO
+    return hipGetLastError();
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
@@ -1438,91 +989,29 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
 {
     if (n_frames <= 0)
         return hipSuccess;
-    const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const int variant = wave1024_variant();
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, variant);
-    dim3 grid((unsigned)chunks), block(kWave1024Threads);
+    const bool packed = wave1024_variant() == 5;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer (AA_W1024_WIDE=0: A/B)
-    static const bool wide_env = [] { const char *e = std::getenv("AA_W1024_WIDE"); return !(e && e[0] == '0'); }();
+    static const bool wide_env = [] {
+        const char *e = std::getenv("AA_W1024_WIDE");
+        return !(e && e[0] == '0');
+    }();
     const bool wide = wide_env && out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
-#define AA_LAUNCH_W1024(KERNEL, K)                                                             \
-    hipLaunchKernelGGL((KERNEL<K>), grid, block, lds, stream, x, out, table, frame_begin,      \
-                       n_frames, hop, frames_per_wg, log_floor)
-#define AA_SWITCH_W1024(KERNEL)                                                                \
-    switch (out_kind) {                                                                        \
-    case kComplex: AA_LAUNCH_W1024(KERNEL, kComplex); break;                                   \
-    case kMag: AA_LAUNCH_W1024(KERNEL, kMag); break;                                           \
-    case kPower: AA_LAUNCH_W1024(KERNEL, kPower); break;                                       \
-    case kLogPower: AA_LAUNCH_W1024(KERNEL, kLogPower); break;                                 \
-    default: return hipErrorInvalidValue;                                                      \
+    switch (out_kind) {
+    case kComplex:
+        return launch_wave1024_kind<kComplex>(packed, wide, x, out, table, frame_begin, n_frames, hop,
+                                              frames_per_wg, log_floor, stream);
+    case kMag:
+        return launch_wave1024_kind<kMag>(packed, wide, x, out, table, frame_begin, n_frames, hop,
+                                          frames_per_wg, log_floor, stream);
+    case kPower:
+        return launch_wave1024_kind<kPower>(packed, wide, x, out, table, frame_begin, n_frames, hop,
+                                            frames_per_wg, log_floor, stream);
+    case kLogPower:
+        return launch_wave1024_kind<kLogPower>(packed, wide, x, out, table, frame_begin, n_frames, hop,
+                                               frames_per_wg, log_floor, stream);
+    default:
+        return hipErrorInvalidValue;
     }
-#define AA_LAUNCH_W1024_V3(K)                                                                  \
-    {                                                                                          \
-        static int cached_grid = 0;                                                            \
-        static size_t cached_lds = 0;                                                          \
-        if (cached_grid == 0 || cached_lds != lds) {                                           \
-            cached_grid = persistent_grid(stft_wave1024_v3_kernel<K>, lds, 1 << 30);           \
-            cached_lds = lds;                                                                  \
-        }                                                                                      \
-        int64_t g = cached_grid < chunks ? cached_grid : chunks;                               \
-        if (variant == 5 && wide)                                                              \
-            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, true>), dim3((unsigned)g), block,    \
-                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
-                               frames_per_wg, chunks, log_floor);                              \
-        else if (variant == 5)                                                                 \
-            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, false>), dim3((unsigned)g), block,   \
-                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
-                               frames_per_wg, chunks, log_floor);                              \
-        else if (wide)                                                                         \
-            hipLaunchKernelGGL((stft_wave1024_v3_kernel<K, 0, true>), dim3((unsigned)g), block,    \
-                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
-                               frames_per_wg, chunks, log_floor);                              \
-        else                                                                                   \
-            hipLaunchKernelGGL((stft_wave1024_v3_kernel<K, 0, false>), dim3((unsigned)g), block,   \
-                               lds, stream, x, out, table, frame_begin, n_frames, hop,         \
-                               frames_per_wg, chunks, log_floor);                              \
-    }
-    if (variant == 4) {
-        const size_t lds4 = sizeof(float) * 4 * kW1024ScratchDwordsV3;
-        static int grid4 = 0;
-        if (grid4 == 0)
-            grid4 = persistent_grid(stft_wave1024_v4_kernel<kMag>, lds4, 1 << 30);
-        const int64_t groups = (n_frames + 3) / 4;
-        const unsigned g = (unsigned)(grid4 < groups ? grid4 : groups);
-        const float *xs = x;
-        float *outs = out;
-        switch (out_kind) {
-        case kComplex:
-            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kComplex>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
-            break;
-        case kMag:
-            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kMag>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
-            break;
-        case kPower:
-            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kPower>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
-            break;
-        case kLogPower:
-            hipLaunchKernelGGL((stft_wave1024_v4_kernel<kLogPower>), dim3(g), block, lds4, stream, xs, outs, table, frame_begin, n_frames, hop, log_floor);
-            break;
-        default: return hipErrorInvalidValue;
-        }
-    } else if (variant == 1) {
-        AA_SWITCH_W1024(stft_wave1024_kernel)
-    } else if (variant == 2) {
-        AA_SWITCH_W1024(stft_wave1024_v2_kernel)
-    } else {
-        switch (out_kind) {
-        case kComplex: AA_LAUNCH_W1024_V3(kComplex); break;
-        case kMag: AA_LAUNCH_W1024_V3(kMag); break;
-        case kPower: AA_LAUNCH_W1024_V3(kPower); break;
-        case kLogPower: AA_LAUNCH_W1024_V3(kLogPower); break;
-        default: return hipErrorInvalidValue;
-        }
-    }
-#undef AA_LAUNCH_W1024_V3
-#undef AA_SWITCH_W1024
-#undef AA_LAUNCH_W1024
-    return hipGetLastError();
 }
 
 hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float *out,

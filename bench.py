@@ -104,8 +104,8 @@ def load_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--skip-cpu", action="store_true", help="omit the cpu_baseline leg (profiling runs)")
     ap.add_argument("--output", default="mag", choices=["mag", "complex", "power", "logpower"])
     args = ap.parse_args()
@@ -144,6 +144,14 @@ def main():
     def step():
         plan.execute_device(xd, 0, nf, out=out, stream=stream.cuda_stream)
 
+    # Device bring-up (not a step): a cold MI355X takes ~30 ms of back-to-back launches to
+    # reach its steady clock / page-table state (first 300 launches measured 90 us each, every
+    # later batch 80 us - tools/launch_overhead.py).  Then the W untimed warm-up steps.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.25:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 static float *dx, *dout, *dtab;
+static unsigned *dcnt;
 static const int hop = 256;
 static const int64_t n_samples = 28800000, n_frames = (n_samples - 1024) / hop + 1;
 
@@ -15,7 +16,7 @@ template <int ABL>
 double run(int fpw, const char *name, int force_per_cu = 0)
 {
     const int64_t chunks = (n_frames + fpw - 1) / fpw;
-    const size_t lds = aa::wave1024_lds_bytes(fpw, hop, 3);
+    const size_t lds = aa::wave1024_lds_bytes(fpw, hop);
     int per_cu = 1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v5_kernel<aa::kMag, ABL, true>, 256, lds);
     if (force_per_cu) per_cu = force_per_cu;
@@ -34,50 +35,20 @@ double run(int fpw, const char *name, int force_per_cu = 0)
         ts.push_back(ms / 20);
     }
     std::sort(ts.begin(), ts.end());
-    printf("fpw %2d  %-44s %d WG/CU  median %.2f us  min %.2f us\n", fpw, name, per_cu, ts[ts.size() / 2] * 1e3, ts[0] * 1e3);
-    return ts[ts.size() / 2];
-}
-
-template <int ABL>
-double run4(const char *name, int wgs_per_cu = 0)
-{
-    const size_t lds = sizeof(float) * 4 * aa::kW1024ScratchDwordsV3;
-    int per_cu = 1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v4_kernel<aa::kMag, ABL>, 256, lds);
-    if (wgs_per_cu > 0) per_cu = wgs_per_cu;
-    int grid = 256 * per_cu;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    std::vector<float> ts;
-    for (int rep = 0; rep < 6; ++rep) {
-        hipEventRecord(e0, 0);
-        for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL((aa::stft_wave1024_v4_kernel<aa::kMag, ABL>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
-                               (int64_t)0, n_frames, hop, 1e-10f);
-        hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        ts.push_back(ms / 20);
-    }
-    std::sort(ts.begin(), ts.end());
     std::vector<unsigned long long> clk(4 * 8192);
     hipMemcpyFromSymbol(clk.data(), HIP_SYMBOL(aa::aa_clk_dbg), clk.size() * 8);
-    std::vector<double> ghz, life, start;
+    std::vector<double> life, start, endt;
     unsigned long long first = ~0ull;
     int nb = grid < 8192 ? grid : 8192;
     for (int b = 0; b < nb; ++b) first = std::min(first, clk[4 * b + 2]);
-    int per_xcc[16] = {0};
     for (int b = 0; b < nb; ++b) {
-        ghz.push_back((double)clk[4 * b] / (double)clk[4 * b + 1] * 0.1);
         life.push_back(clk[4 * b + 1] * 0.01);
         start.push_back((clk[4 * b + 2] - first) * 0.01);
-        per_xcc[(clk[4 * b + 3] >> 32) & 15]++;
+        endt.push_back((clk[4 * b + 2] - first + clk[4 * b + 1]) * 0.01);
     }
-    std::sort(ghz.begin(), ghz.end()); std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end());
-    printf("v4      %-40s %d WG/CU  median %.2f us  clock %.2f GHz  WG life min/med/max %.1f/%.1f/%.1f us  start med/p90/max %.1f/%.1f/%.1f us  xcc:", name, per_cu,
-           ts[ts.size() / 2] * 1e3, ghz[nb / 2], life[0], life[nb / 2], life[nb - 1], start[nb / 2], start[nb * 9 / 10], start[nb - 1]);
-    for (int i = 0; i < 8; ++i) printf(" %d", per_xcc[i]);
-    printf("\n");
+    std::sort(life.begin(), life.end()); std::sort(endt.begin(), endt.end());
+    printf("fpw %2d  %-40s %d WG/CU  median %.2f us  min %.2f us | WG life min/med/max %.1f/%.1f/%.1f  end p10/p50/p90/max %.1f/%.1f/%.1f/%.1f\n",
+           fpw, name, per_cu, ts[ts.size() / 2] * 1e3, ts[0] * 1e3, life[0], life[nb / 2], life[nb - 1], endt[nb / 10], endt[nb / 2], endt[nb * 9 / 10], endt[nb - 1]);
     return ts[ts.size() / 2];
 }
 
@@ -99,10 +70,12 @@ int main(int argc, char **argv)
         }
         for (int j = 0; j < 4; ++j) { double th = 2.0 * kPi * (lane + 64 * j) / 1024.0; tab[(44 + 2 * j) * 64 + lane] = -sin(th); tab[(45 + 2 * j) * 64 + lane] = -cos(th); }
     }
+    hipMalloc(&dcnt, 256);
     hipMalloc(&dx, n_samples * 4); hipMalloc(&dout, n_frames * 513 * 4); hipMalloc(&dtab, tab.size() * 4);
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
-    for (int pc : {2, 4, 5}) run<0>(fpw, "full kernel", pc);
+    for (int i = 0; i < 8; ++i) run<0>(fpw, "warm-up (ignore)");
+    for (int pc : {2, 3, 4, 5}) run<0>(fpw, "full kernel", pc);
     for (int pc : {2, 4, 5}) run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only", pc);
     for (int pc : {2, 4, 5}) run<1 | 8 | 32>(fpw, "no stores/DMA/barrier", pc);
     run<1>(fpw, "no global stores");

@@ -31,15 +31,15 @@ int main(int argc, char **argv)
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
     const int64_t chunks = (n_frames + fpw - 1) / fpw;
-    const size_t lds = aa::wave1024_lds_bytes(fpw, hop, 3);
+    const size_t lds = aa::wave1024_lds_bytes(fpw, hop);
     int per_cu = 1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v3_kernel<aa::kMag>, 256, lds);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v3_kernel<aa::kMag, 0, true>, 256, lds);
     int grid = 256 * per_cu;
     hipMalloc(&ddbg, (size_t)grid * 4 * 12 * 8);
     printf("fpw %d lds %zu B, %d WG/CU, grid %d\n", fpw, lds, per_cu, grid);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(ddbg, 0, (size_t)grid * 4 * 12 * 8);
-        hipLaunchKernelGGL((aa::stft_wave1024_v3_kernel<aa::kMag>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+        hipLaunchKernelGGL((aa::stft_wave1024_v3_kernel<aa::kMag, 0, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
                            (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, ddbg);
         hipDeviceSynchronize();
     }
