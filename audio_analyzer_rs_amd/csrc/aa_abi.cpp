@@ -3,6 +3,7 @@
 #include "../../include/aa_stft.h"
 #include "aa_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -143,6 +144,43 @@ void build_wave1024_table(const float *window, std::vector<float> *tab)
     }
 }
 
+constexpr int64_t kMelSlab = 8192;   // frames per power-spectrogram slab (stays L2/MALL resident)
+
+// Slaney mel scale (linear below 1 kHz, log above) — the build's definition of AA_OUT_LOGMEL
+// (the reference has no mel stage); oracle/truth.py holds the float64 twin.
+double hz_to_mel(double f)
+{
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m)
+{
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+// Slaney-normalised triangular filters, row-major [n_mels][n_bins], float64.
+void mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax, std::vector<double> *w)
+{
+    const int nb = n_fft / 2 + 1;
+    w->assign((size_t)n_mels * nb, 0.0);
+    std::vector<double> hz(n_mels + 2);
+    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i)
+        hz[i] = mel_to_hz(m0 + (m1 - m0) * (double)i / (double)(n_mels + 1));
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (hz[i + 2] - hz[i]);
+        for (int k = 0; k < nb; ++k) {
+            const double f = (double)k * sr / n_fft;
+            const double lower = (f - hz[i]) / (hz[i + 1] - hz[i]);
+            const double upper = (hz[i + 2] - f) / (hz[i + 2] - hz[i + 1]);
+            const double v = std::min(lower, upper);
+            (*w)[(size_t)i * nb + k] = v > 0.0 ? v * enorm : 0.0;
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- plan structs --
@@ -166,6 +204,13 @@ struct aa_stft_plan {
     bool wave1024 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
+    // mel / MFCC post-ops (build-defined)
+    int n_mels = 0, n_mels_pad = 0, n_mfcc = 0;
+    float *d_melT = nullptr;       // [n_bins_pad x n_mels_pad]
+    int *d_tile_k = nullptr;       // [n_mels_pad/32][2]
+    float *d_dct = nullptr;        // [n_mfcc x n_mels]
+    float *d_ws_power = nullptr;   // [kMelSlab x n_bins]
+    float *d_ws_logmel = nullptr;  // [kMelSlab x n_mels]
     // host-execute workspace
     float *d_ws_in = nullptr;
     size_t ws_in_floats = 0;
@@ -330,8 +375,12 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
         return fail(AA_ERR_ARG, "AA_WINDOW_CUSTOM needs custom_window_host");
     if (cfg->output < AA_OUT_COMPLEX || cfg->output > AA_OUT_MFCC)
         return fail(AA_ERR_ARG, "unknown output kind %d", cfg->output);
-    if (cfg->output == AA_OUT_LOGMEL || cfg->output == AA_OUT_MFCC)
-        return fail(AA_ERR_UNSUPPORTED, "mel / MFCC outputs are not built yet");
+    const bool mel_out = cfg->output == AA_OUT_LOGMEL || cfg->output == AA_OUT_MFCC;
+    if (mel_out && (cfg->n_mels <= 0 || cfg->n_mels > 4096 || cfg->sample_rate <= 0))
+        return fail(AA_ERR_ARG, "mel output needs 0 < n_mels <= 4096 and a sample rate (got %d, %d)",
+                    cfg->n_mels, cfg->sample_rate);
+    if (cfg->output == AA_OUT_MFCC && (cfg->n_mfcc <= 0 || cfg->n_mfcc > cfg->n_mels))
+        return fail(AA_ERR_ARG, "MFCC needs 0 < n_mfcc <= n_mels (got %d)", cfg->n_mfcc);
 
     aa_stft_plan *p = new (std::nothrow) aa_stft_plan();
     if (!p)
@@ -339,7 +388,10 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
     p->cfg = *cfg;
     p->log_floor = cfg->log_floor > 0.0f ? cfg->log_floor : 1e-10f;
     const int nb = cfg->n_fft / 2 + 1;
-    p->out_cols = cfg->output == AA_OUT_COMPLEX ? 2 * nb : nb;
+    p->out_cols = cfg->output == AA_OUT_COMPLEX  ? 2 * nb
+                  : cfg->output == AA_OUT_LOGMEL ? cfg->n_mels
+                  : cfg->output == AA_OUT_MFCC   ? cfg->n_mfcc
+                                                 : nb;
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) {
         delete p;
@@ -361,6 +413,53 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
         int r = build_fft_tables(cfg->n_fft, &p->tabs);
         if (r != AA_OK)
             return r;
+        if (mel_out) {
+            const int n_mels = cfg->n_mels, n_mels_pad = (n_mels + 31) / 32 * 32;
+            const int nb_pad = (nb + 63) / 64 * 64;
+            const double fmax = cfg->fmax > 0.0f ? cfg->fmax : cfg->sample_rate / 2.0;
+            std::vector<double> w;
+            mel_filterbank(cfg->sample_rate, cfg->n_fft, n_mels, cfg->fmin, fmax, &w);
+            std::vector<float> melT((size_t)nb_pad * n_mels_pad, 0.0f);
+            std::vector<int> tile_k(2 * (n_mels_pad / 32));
+            for (int t = 0; t < n_mels_pad / 32; ++t) {
+                int lo = nb_pad, hi = 0;
+                for (int m = 32 * t; m < 32 * t + 32 && m < n_mels; ++m)
+                    for (int k = 0; k < nb; ++k)
+                        if (w[(size_t)m * nb + k] != 0.0) {
+                            lo = std::min(lo, k);
+                            hi = std::max(hi, k + 1);
+                        }
+                if (hi <= lo)
+                    lo = hi = 0;
+                tile_k[2 * t] = lo / 64 * 64;
+                tile_k[2 * t + 1] = (hi + 63) / 64 * 64;
+            }
+            for (int m = 0; m < n_mels; ++m)
+                for (int k = 0; k < nb; ++k)
+                    melT[(size_t)k * n_mels_pad + m] = (float)w[(size_t)m * nb + k];
+            p->n_mels = n_mels;
+            p->n_mels_pad = n_mels_pad;
+            p->n_mfcc = cfg->n_mfcc;
+            AA_HIP(hipMalloc(&p->d_melT, melT.size() * sizeof(float)));
+            AA_HIP(hipMemcpy(p->d_melT, melT.data(), melT.size() * sizeof(float), hipMemcpyHostToDevice));
+            AA_HIP(hipMalloc(&p->d_tile_k, tile_k.size() * sizeof(int)));
+            AA_HIP(hipMemcpy(p->d_tile_k, tile_k.data(), tile_k.size() * sizeof(int), hipMemcpyHostToDevice));
+            AA_HIP(hipMalloc(&p->d_ws_power, sizeof(float) * (size_t)kMelSlab * nb));
+            if (cfg->output == AA_OUT_MFCC) {
+                // DCT-II, orthonormal: d[c][m] = s_c cos(pi c (2m+1) / (2M)), s_0 = sqrt(1/M), else sqrt(2/M)
+                std::vector<float> dct((size_t)cfg->n_mfcc * n_mels);
+                for (int c = 0; c < cfg->n_mfcc; ++c)
+                    for (int m = 0; m < n_mels; ++m) {
+                        double v = std::cos(kPi * c * (2.0 * m + 1.0) / (2.0 * n_mels)) * std::sqrt(2.0 / n_mels);
+                        if (c == 0)
+                            v *= std::sqrt(0.5);
+                        dct[(size_t)c * n_mels + m] = (float)v;
+                    }
+                AA_HIP(hipMalloc(&p->d_dct, dct.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_dct, dct.data(), dct.size() * sizeof(float), hipMemcpyHostToDevice));
+                AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)kMelSlab * n_mels));
+            }
+        }
         if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
             // frames per workgroup chunk: the tunable default, shrunk until the LDS need fits 64 KiB.
             int fpw = 8;
@@ -395,7 +494,8 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
         return AA_OK;
     DeviceGuard g(p->device);
     free_fft_tables(&p->tabs);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out};
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct,
+                     p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k)};
     for (float *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -443,14 +543,35 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
     if (!g.ok)
         return fail(AA_ERR_HIP, "cannot select device %d", p->device);
     hipStream_t st = (hipStream_t)stream;
-    const float *first = samples_dev + frame_begin * (int64_t)p->cfg.hop;
-    if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
-        AA_HIP(aa::launch_wave1024(p->cfg.output, samples_dev, out_dev, p->d_w1024_tab, frame_begin,
-                                   nf, p->cfg.hop, p->frames_per_wg, p->log_floor, st));
-    } else {
-        AA_HIP(aa::launch_generic_forward(p->tabs.pow2, p->cfg.output, samples_dev, out_dev,
-                                          p->d_window, p->tabs.tw_m, p->tabs.tw_split, p->cfg.n_fft,
-                                          frame_begin, nf, p->cfg.hop, p->log_floor, st));
+    // The FFT stage: frames [fb, fb+n) -> rows of `dst` in output kind `kind`.
+    auto fft_stage = [&](int kind, int64_t fb, int64_t n, float *dst) -> int {
+        const float *first = samples_dev + fb * (int64_t)p->cfg.hop;
+        if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+            AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                       p->frames_per_wg, p->log_floor, st));
+        } else {
+            AA_HIP(aa::launch_generic_forward(p->tabs.pow2, kind, samples_dev, dst, p->d_window,
+                                              p->tabs.tw_m, p->tabs.tw_split, p->cfg.n_fft, fb, n,
+                                              p->cfg.hop, p->log_floor, st));
+        }
+        return AA_OK;
+    };
+    if (p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC)
+        return fft_stage(p->cfg.output, frame_begin, nf, out_dev);
+    // mel / MFCC: power spectrogram slab -> f32 MFMA filterbank (+log) -> optional DCT.
+    // The slab (<= 34 MB) is re-read by the next kernel out of L2 / Infinity Cache.
+    const int nb = p->cfg.n_fft / 2 + 1;
+    for (int64_t f = 0; f < nf; f += kMelSlab) {
+        const int64_t n = std::min<int64_t>(kMelSlab, nf - f);
+        int rc = fft_stage(aa::kPower, frame_begin + f, n, p->d_ws_power);
+        if (rc != AA_OK)
+            return rc;
+        float *mel_dst = p->cfg.output == AA_OUT_MFCC ? p->d_ws_logmel : out_dev + f * p->n_mels;
+        AA_HIP(aa::launch_mel(true, p->d_ws_power, p->d_melT, p->d_tile_k, mel_dst, n, nb, p->n_mels,
+                              p->n_mels_pad, p->log_floor, st));
+        if (p->cfg.output == AA_OUT_MFCC)
+            AA_HIP(aa::launch_dct_rows(p->d_ws_logmel, p->d_dct, out_dev + f * p->n_mfcc, n, p->n_mels,
+                                       p->n_mfcc, st));
     }
     return AA_OK;
 }
@@ -493,6 +614,16 @@ int aa_stft_execute_host(aa_stft_plan *p, const float *samples_host, int64_t n_s
     AA_HIP(hipMemcpyAsync(out_host, p->d_ws_out, sizeof(float) * (size_t)nf * p->out_cols,
                           hipMemcpyDeviceToHost, nullptr));
     AA_HIP(hipStreamSynchronize(nullptr));
+    return AA_OK;
+}
+
+// ----------------------------------------------------------------------- downmix --
+int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t channels,
+                      float *mono_dev, void *stream)
+{
+    if (!interleaved_dev || !mono_dev || n_frames < 0 || channels <= 0)
+        return fail(AA_ERR_ARG, "aa_downmix_device: bad argument");
+    AA_HIP(aa::launch_downmix(interleaved_dev, mono_dev, n_frames, channels, (hipStream_t)stream));
     return AA_OK;
 }
 

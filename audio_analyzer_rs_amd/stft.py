@@ -100,6 +100,23 @@ class Stft:
         return out
 
 
+def downmix(interleaved, channels, stream=None):
+    """Average the first min(channels, 2) channels of an interleaved CUDA float32 tensor to
+    mono — what the capture callback does before the STFT workers see a slot
+    (src/audio_io/mod.rs:784-794)."""
+    import torch
+
+    lib = _lib.load()
+    if not (interleaved.is_cuda and interleaved.dtype == torch.float32 and interleaved.is_contiguous()):
+        raise _lib.AaError(_lib.AA_ERR_ARG, "interleaved must be a contiguous CUDA float32 tensor")
+    n = interleaved.numel() // int(channels)
+    out = torch.empty(n, dtype=torch.float32, device=interleaved.device)
+    st = stream if stream is not None else torch.cuda.current_stream(interleaved.device).cuda_stream
+    if n:
+        _lib.check(lib.aa_downmix_device(interleaved.data_ptr(), n, int(channels), out.data_ptr(), st))
+    return out
+
+
 class StftStream:
     """Streaming front end: the ring-buffer ingest of stft.rs:198-201, 240-266 feeding the
     GPU frame loop.  `push(slot)` appends one slot (the reference's are 1024 samples,

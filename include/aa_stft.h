@@ -104,7 +104,9 @@ enum {
     AA_OUT_MAG = 1,      /* |X| = c.norm(), n_fft/2+1 floats (stft.rs:314-318, onset.rs:271) */
     AA_OUT_POWER = 2,    /* |X|^2                         — build-defined, not in reference  */
     AA_OUT_LOGPOWER = 3, /* 10*log10(max(|X|^2, floor))   — build-defined, not in reference  */
-    AA_OUT_LOGMEL = 4,   /* 10*log10(max(mel @ |X|^2, floor)), n_mels floats — build-defined */
+    AA_OUT_LOGMEL = 4,   /* 10*log10(max(mel @ |X|^2, floor)), n_mels floats — build-defined:
+                            Slaney mel scale, Slaney-normalised triangles, fmin..fmax, on the
+                            f32 matrix cores (oracle/truth.py holds the float64 definition)    */
     AA_OUT_MFCC = 5      /* DCT-II(ortho) of log-mel, n_mfcc floats      — build-defined     */
 };
 
@@ -149,6 +151,13 @@ int aa_stft_execute_device(aa_stft_plan *plan, const float *samples_dev, int64_t
  * plan's workspace).  out_host holds aa_stft_num_frames * aa_stft_out_cols floats. */
 int aa_stft_execute_host(aa_stft_plan *plan, const float *samples_host, int64_t n_samples,
                          float *out_host);
+
+/* ---- capture-side downmix (src/audio_io/mod.rs:784-794) -------------------- */
+/* mono[i] = (sum of the first min(channels, 2) channels of frame i) / that count: what the
+ * input callback does before a slot reaches the STFT workers (the reference never runs a
+ * multi-channel STFT).  interleaved_dev holds n_frames * channels floats. */
+int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t channels,
+                      float *mono_dev, void *stream);
 
 /* ---- frame-range sharding (one rank per GPU) --------------- */
 /* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs

@@ -172,6 +172,81 @@ def test_windows_rect_and_custom(aa, oracle_mod, torch_mod):
     assert nerr(got, ref).max() < TOL_VS_TRUTH
 
 
+# ------------------------------------ build-defined post-ops: log-mel, MFCC, downmix --
+def _logmel_truth(oracle_mod, x, n, hop, sr, n_mels, floor=1e-10):
+    tr = oracle_mod.truth
+    P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+    M = P @ tr.mel_filterbank(sr, n, n_mels).T
+    return M, 10.0 * np.log10(np.maximum(M, floor))
+
+
+@pytest.mark.parametrize("n,hop", [(2048, 512), (1024, 256)])
+def test_logmel_two_channels(aa, oracle_mod, torch_mod, n, hop):
+    """BASELINE config 3 (2048-pt + 128-bin log-mel on synthetic stereo), small size.  The
+    reference has no mel stage: parity is against the build's own float64 definition."""
+    sr, n_mels = 48000, 128
+    plan = aa.Stft(n, hop, output="logmel", sample_rate=sr, n_mels=n_mels)
+    assert plan.cols == n_mels
+    for seed in (12345, 54321):
+        x = aa.signals.synth_corpus(0, n + 199 * hop, seed=seed)
+        M, L = _logmel_truth(oracle_mod, x, n, hop, sr, n_mels)
+        got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+        assert got.shape == L.shape == (200, n_mels)
+        # linear-domain max-normalised criterion after undoing the log, dB on strong bins
+        assert nerr(10.0 ** (got.astype(np.float64) / 10.0), np.maximum(M, 1e-10)).max() < 2e-5
+        near = L >= L.max(axis=1, keepdims=True) - 40.0
+        assert np.max(np.abs(got - L)[near]) < 1e-3
+    # host path and slab boundary (more than one 8192-frame slab)
+    x = aa.signals.synth_corpus(7, n + 8500 * hop)
+    got = plan(x)
+    _, L = _logmel_truth(oracle_mod, x[(8190 * hop):], n, hop, sr, n_mels)
+    near = L >= L.max(axis=1, keepdims=True) - 40.0
+    assert np.max(np.abs(got[8190:] - L)[near]) < 1e-3
+
+
+def test_mfcc_sine_and_chirp(aa, oracle_mod, torch_mod):
+    """BASELINE config 5: 40-coef MFCC (STFT -> mel -> log -> DCT-II) on a 440 Hz sine and a
+    50 Hz -> 12 kHz chirp, 10 s.  tol 1e-5 max-normalised per frame vs the float64 definition.
+    A -60 dB dither keeps every mel band above the f32 FFT's own rounding floor (a pure tone's
+    empty bands sit at ~1e-14 of the peak in float64 and at ~1e-10 in ANY f32 transform, so
+    their dB values are not comparable); with a pure tone the log floor is raised instead."""
+    sr, n, hop, n_mels, n_mfcc = 48000, 1024, 256, 128, 40
+    tr = oracle_mod.truth
+    dct = tr.dct2_ortho(n_mfcc, n_mels)
+    rng = np.random.default_rng(1)
+    dither = (1e-3 * rng.standard_normal(10 * sr)).astype(np.float32)
+    for sig in (aa.signals.sine(440.0, 10 * sr), aa.signals.chirp(50.0, 12000.0, 10 * sr)):
+        x = (sig + dither).astype(np.float32)
+        plan = aa.Stft(n, hop, output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc)
+        got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+        _, L = _logmel_truth(oracle_mod, x, n, hop, sr, n_mels)
+        ref = L @ dct.T
+        assert got.shape == ref.shape == (plan.num_frames(len(x)), n_mfcc)
+        assert nerr(got, ref).max() < 1e-5
+        # pure signal, floor above the f32 noise of the empty bands
+        plan_f = aa.Stft(n, hop, output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc, log_floor=1e-3)
+        got = plan_f(torch_mod.from_numpy(sig[:sr]).cuda()).cpu().numpy()
+        _, L = _logmel_truth(oracle_mod, sig[:sr], n, hop, sr, n_mels, floor=1e-3)
+        assert nerr(got, L @ dct.T).max() < 1e-5
+
+
+def test_mel_argument_errors(aa):
+    with pytest.raises(aa.AaError):
+        aa.Stft(1024, 256, output="logmel", n_mels=0)
+    with pytest.raises(aa.AaError):
+        aa.Stft(1024, 256, output="mfcc", n_mels=40, n_mfcc=41)
+
+
+def test_downmix_matches_capture_rule(aa, torch_mod):
+    g = torch_mod.Generator(device="cuda").manual_seed(3)
+    for ch in (1, 2, 3, 6):
+        x = torch_mod.rand((10_001, ch), generator=g, device="cuda") * 2 - 1
+        got = aa.downmix(x.reshape(-1).contiguous(), ch)
+        use = min(ch, 2)                                  # mod.rs:784: channels_to_use = min(channels, 2)
+        ref = x[:, :use].sum(dim=1) / use if use > 1 else x[:, 0]
+        assert torch_mod.allclose(got, ref, rtol=0, atol=1e-7)
+
+
 # --------------------------------------------------------- FftProcessor (fft.rs:6-42) --
 @pytest.mark.parametrize("n", [4, 16, 256, 1024, 2048, 8192, 6, 100])
 def test_fft_processor_forward_inverse(aa, oracle_mod, n):
