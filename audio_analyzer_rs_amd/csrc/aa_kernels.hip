@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v3_kernel(
 // sweeps of the ablated kernel showed the compute side saturating the VALU (~2.8 cycles
 // per scalar op in situ): packing halves the instruction count of the butterflies,
 // twiddles and the split.
-template <int OUT, int ABL = 0, bool WIDE = false>
+template <int OUT, int ABL = 0, bool WIDE = false, bool TWO = true>
 __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
@@ -542,29 +542,37 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     AA_CLK_BEGIN
 
-    const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
-    const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
+    // This workgroup's run of chunks [c0, c1).  Everything per chunk below is 32-bit scalar
+    // arithmetic on running pointers (a lone wave issues a scalar instruction only every few
+    // cycles: the 64-bit multiplies of the first version cost ~450 cycles per frame).
+    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
+    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
+    constexpr int NB = 513;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+    const int64_t first_frame = (int64_t)c0 * frames_per_wg;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
+    float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
+    int frames_left = (int)(n_frames - first_frame);                            // from chunk c on
+    const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
 
-    auto stage = [&](int64_t c, int which) {
-        const int64_t f0 = c * frames_per_wg;
-        const int64_t left = n_frames - f0;
-        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
-        const int span4 = ((nf - 1) * hop + 1024) >> 2;
-        const float *src = x + (frame_begin + f0) * (int64_t)hop;
+    // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
+    // (wave w moves the 1 KiB pieces w, w+4, ..)
+    auto stage = [&](const float *src, int nfc, int which) {
+        const int span4 = ((nfc - 1) * hop + 1024) >> 2;
         float *dst = smem + which * max_span;
         for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int q = qb + lane;
             if (q < span4)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + 4 * (int64_t)q),
+                    (const __attribute__((address_space(1))) void *)(src + 4 * q),
                     (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
         }
     };
 
     if (c0 < c1)
-        stage(c0, 0);
+        stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
 
     // per-lane constants as packed pairs
     v2f win[8], twA[8], twB[8], tws[4];
@@ -583,10 +591,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
 
-    for (int64_t c = c0; c < c1; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
         if ((ABL & 64) || c == c0 || frames_per_wg != 8)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -594,47 +600,50 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        if (c + 1 < c1 && !(ABL & 8))
-            stage(c + 1, cur ^ 1);
-
-        const int64_t f0 = c * frames_per_wg;
-        const int64_t left = n_frames - f0;
-        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
+        const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        if (c + 1 < c1 && !(ABL & 8)) {
+            const int nleft = frames_left - frames_per_wg;
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+        }
+        const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
 
-        for (int t = wave; t < nf; t += 4) {
+        // ---- per-frame phases (lambdas so that two frames can be interleaved) ----------
+        auto read_frame = [&](int t, v2f (&v)[8]) {
             const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
-            v2f v[8];
-            {
-                v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<512>(fr), s2 = lds_read_b64<1024>(fr),
-                    s3 = lds_read_b64<1536>(fr), s4 = lds_read_b64<2048>(fr), s5 = lds_read_b64<2560>(fr),
-                    s6 = lds_read_b64<3072>(fr), s7 = lds_read_b64<3584>(fr);
-                lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
-                v[0] = s0 * win[0]; v[1] = s1 * win[1]; v[2] = s2 * win[2]; v[3] = s3 * win[3];
-                v[4] = s4 * win[4]; v[5] = s5 * win[5]; v[6] = s6 * win[6]; v[7] = s7 * win[7];
-            }
+            v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<512>(fr); v[2] = lds_read_b64<1024>(fr);
+            v[3] = lds_read_b64<1536>(fr); v[4] = lds_read_b64<2048>(fr); v[5] = lds_read_b64<2560>(fr);
+            v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
+        };
+        auto pass_a = [&](v2f (&v)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = v[j] * win[j];
             pk_dft8(v);
 #pragma unroll
-            for (int k = 1; k < 8; ++k)
-                v[k] = pk_cmul(v[k], twA[k]);
-            // ---- E1 through LDS ----
-            if (!(ABL & 4)) {
+            for (int kk = 1; kk < 8; ++kk)
+                v[kk] = pk_cmul(v[kk], twA[kk]);
+        };
+        auto exchange1 = [&](v2f (&v)[8]) {           // E1 through LDS
+            if (ABL & 4)
+                return;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    e1_wr[8 * k] = v[k];
-                __builtin_amdgcn_wave_barrier();
+            for (int kk = 0; kk < 8; ++kk)
+                e1_wr[8 * kk] = v[kk];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v4f qv = e1_rd[i];
-                    v[2 * i] = v2f{qv.x, qv.y};
-                    v[2 * i + 1] = v2f{qv.z, qv.w};
-                }
-                __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < 4; ++i) {
+                v4f qv = e1_rd[i];
+                v[2 * i] = v2f{qv.x, qv.y};
+                v[2 * i + 1] = v2f{qv.z, qv.w};
             }
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto pass_bc = [&](v2f (&v)[8]) {
             pk_dft8(v);
 #pragma unroll
-            for (int k = 1; k < 8; ++k)
-                v[k] = pk_cmul(v[k], twB[k]);
+            for (int kk = 1; kk < 8; ++kk)
+                v[kk] = pk_cmul(v[kk], twB[kk]);
             if (!(ABL & 2)) {
                 // the DPP / permlane moves read registers the packed asm just wrote: keep the
                 // two wait states the hazard rules ask for (the compiler cannot see into asm)
@@ -642,9 +651,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
                 exchange_high(v);
             }
             pk_dft8(v);
-
-            // ---- split ----
-            v2f prt[4];
+        };
+        auto strip = [&](v2f (&v)[8], v2f (&prt)[4]) {   // partner half through the LDS strip
             if (!(ABL & 16)) {
 #pragma unroll
                 for (int j = 4; j < 8; ++j)
@@ -655,12 +663,17 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     prt[j] = scr[256 - (lane + 64 * j)];
+                __builtin_amdgcn_wave_barrier();
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     prt[j] = v[7 - j];
             }
-            float *row = out + (f0 + t) * (int64_t)COLS;
+        };
+        auto epilogue = [&](v2f (&v)[8], v2f (&prt)[4], int t, bool valid) {
+            // ABL 256: all rows land in the first 32 rows of `out` (L2-resident): same store
+            // instructions, no HBM write stream
+            float *row = (ABL & 256) ? out + ((row0 + t) & 31) * COLS : out_chunk + t * COLS;
             v2f xk[4], xm[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -670,62 +683,110 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
                 xm[j] = e - tt;                                  // X[512-k] = conj(xm)
             }
             if (OUT == kComplex) {
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kk = lane + 64 * j;
+                        reinterpret_cast<v2f *>(row)[kk] = xk[j];
+                        reinterpret_cast<v2f *>(row)[512 - kk] = v2f{xm[j].x, -xm[j].y};
+                    }
+                    if (lane == 0)
+                        reinterpret_cast<v2f *>(row)[256] = v2f{2.0f * v[4].x, -2.0f * v[4].y};
+                }
+                return;
+            }
+            float mk[4], mm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
+                mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+            }
+            const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+            if (ABL & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("" ::"v"(mk[j]), "v"(mm[j]));
+            } else if (WIDE) {
+                // Row through LDS so it leaves as 16-byte-aligned nontemporal dwordx4 stores.
+                // The row starts at float 513 r of a 16-byte-aligned buffer, so its aligned
+                // window begins sh = r & 3 floats earlier; LDS float i <-> global float
+                // 513 r - sh + i.
+                const int sh = (row0 + t) & 3;
+                float *lrow = reinterpret_cast<float *>(scr) + sh;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = lane + 64 * j;
-                    reinterpret_cast<v2f *>(row)[k] = xk[j];
-                    reinterpret_cast<v2f *>(row)[512 - k] = v2f{xm[j].x, -xm[j].y};
+                    lrow[lane + 64 * j] = mk[j];
+                    lrow[512 - lane - 64 * j] = mm[j];
                 }
                 if (lane == 0)
-                    reinterpret_cast<v2f *>(row)[256] = v2f{2.0f * v[4].x, -2.0f * v[4].y};
-            } else {
-                float mk[4], mm[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
-                    mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
-                }
-                const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
-                if (ABL & 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        asm volatile("" ::"v"(mk[j]), "v"(mm[j]));
-                } else if (WIDE) {
-                    // aligned nontemporal row stores through LDS (see variant 3)
-                    const int sh = (int)((f0 + t) & 3);
-                    float *lrow = reinterpret_cast<float *>(scr) + sh;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        lrow[lane + 64 * j] = mk[j];
-                        lrow[512 - lane - 64 * j] = mm[j];
-                    }
-                    if (lane == 0)
-                        lrow[256] = m256;
-                    __builtin_amdgcn_wave_barrier();
-                    const float *lw = reinterpret_cast<const float *>(scr);
-                    float *gw = row - sh;
-                    v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                    lrow[256] = m256;
+                __builtin_amdgcn_wave_barrier();
+                const float *lw = reinterpret_cast<const float *>(scr);
+                float *gw = row - sh;
+                v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
+                const int hi = lane < 4 ? lane : 508 + lane;
+                const float hv = lw[lane < 8 ? hi : 0];
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
                     __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
-                    if (lane < 63) {
-                        v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * lane);
+                    if (lane < 63)
                         __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                    }
-                    const int hi = lane < 4 ? lane : 508 + lane;
+                    // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
                     const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
                     if (ok)
-                        gw[hi] = lw[hi];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        row[lane + 64 * j] = mk[j];
-                        row[512 - lane - 64 * j] = mm[j];
-                    }
-                    if (lane == 0)
-                        row[256] = m256;
+                        gw[hi] = hv;
                 }
+            } else if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    row[lane + 64 * j] = mk[j];
+                    row[512 - lane - 64 * j] = mm[j];
+                }
+                if (lane == 0)
+                    row[256] = m256;
             }
-            __builtin_amdgcn_wave_barrier();
+        };
+
+        if (TWO && frames_per_wg == 8) {
+            // Two frames of this wave (t = wave and wave + 4) interleaved phase by phase: the
+            // independent work of one frame fills the LDS round trips and VALU dependency stalls
+            // of the other.  The single scratch area is safe: DS operations of a wave execute in
+            // program order, and each exchange's reads are issued before the next one's writes.
+            const int ta = wave, tb = wave + 4;
+            if (ta < nf) {
+                const bool vb = tb < nf;   // ragged last chunk: B computes on stale LDS, stores nothing
+                v2f va[8], vbv[8], pa[4], pb[4];
+                read_frame(ta, va);
+                read_frame(tb, vbv);
+                lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                pass_a(va);
+                exchange1(va);
+                pass_a(vbv);
+                exchange1(vbv);
+                pass_bc(va);
+                strip(va, pa);
+                pass_bc(vbv);
+                strip(vbv, pb);
+                epilogue(va, pa, ta, true);
+                epilogue(vbv, pb, tb, vb);
+            }
+        } else {
+            for (int t = wave; t < nf; t += 4) {
+                v2f v[8], prt[4];
+                read_frame(t, v);
+                lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                pass_a(v);
+                exchange1(v);
+                pass_bc(v);
+                strip(v, prt);
+                epilogue(v, prt, t, true);
+            }
         }
+        src_chunk += src_stride;
+        out_chunk += out_stride;
+        frames_left -= frames_per_wg;
     }
     AA_CLK_END
 }
@@ -971,7 +1032,19 @@ static hipError_t launch_wave1024_kind(bool packed, bool wide, const float *x, f
 #define AA_GO(KERNEL, W)                                                                       \
     hipLaunchKernelGGL((KERNEL<K, 0, W>), grid, block, lds, stream, x, out, table, frame_begin, \
                        n_frames, hop, frames_per_wg, chunks, log_floor)
-    if (packed && wide)
+    // AA_W1024_TWO=0: one frame at a time per wave (A/B runs only)
+    static const bool two_env = [] {
+        const char *e = std::getenv("AA_W1024_TWO");
+        return !(e && e[0] == '0');
+    }();
+    if (packed && !two_env) {
+        if (wide)
+            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, true, false>), grid, block, lds, stream, x, out,
+                               table, frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+        else
+            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, false, false>), grid, block, lds, stream, x, out,
+                               table, frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+    } else if (packed && wide)
         AA_GO(stft_wave1024_v5_kernel, true);
     else if (packed)
         AA_GO(stft_wave1024_v5_kernel, false);

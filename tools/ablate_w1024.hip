@@ -75,7 +75,12 @@ int main(int argc, char **argv)
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < 8; ++i) run<0>(fpw, "warm-up (ignore)");
-    for (int pc : {2, 3, 4, 5}) run<0>(fpw, "full kernel", pc);
+    run<0>(fpw, "full kernel");
+    run<256>(fpw, "stores hit 32 L2-resident rows");
+    run<1>(fpw, "no stores");
+    run<0>(fpw, "full kernel");
+    run<256>(fpw, "stores hit 32 L2-resident rows");
+    run<1>(fpw, "no stores");
     for (int pc : {2, 4, 5}) run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only", pc);
     for (int pc : {2, 4, 5}) run<1 | 8 | 32>(fpw, "no stores/DMA/barrier", pc);
     run<1>(fpw, "no global stores");
