@@ -181,6 +181,37 @@ void mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax, std
     }
 }
 
+// Per-lane constants of the wave-per-frame 2048 kernel, [kWave2048Rows][64] (row meaning in
+// aa_kernels.hip above stft_wave2048_kernel).
+void build_wave2048_table(const float *window, std::vector<float> *tab)
+{
+    tab->assign((size_t)aa::kWave2048Rows * 64, 0.0f);
+    float *T = tab->data();
+    for (int lane = 0; lane < 64; ++lane) {
+        const int b = lane >> 3;
+        for (int j = 0; j < 8; ++j)
+            for (int c = 0; c < 4; ++c)
+                T[(4 * j + c) * 64 + lane] = 0.5f * window[4 * (64 * j + lane) + c];
+        for (int k = 1; k < 8; ++k) {
+            double aA = -2.0 * kPi * (double)(lane * k) / 512.0;
+            T[(32 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aA);
+            T[(33 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aA);
+            double aB = -2.0 * kPi * (double)(b * k) / 64.0;
+            T[(46 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aB);
+            T[(47 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aB);
+        }
+        for (int j = 0; j < 8; ++j) {
+            const int kk = lane + 64 * j;
+            double ac = -2.0 * kPi * (double)kk / 1024.0;
+            T[(60 + 2 * j) * 64 + lane] = (float)std::cos(ac);
+            T[(61 + 2 * j) * 64 + lane] = (float)std::sin(ac);
+            double th = 2.0 * kPi * (double)kk / 2048.0;
+            T[(76 + 2 * j) * 64 + lane] = (float)(-std::sin(th));
+            T[(77 + 2 * j) * 64 + lane] = (float)(-std::cos(th));
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- plan structs --
@@ -200,7 +231,8 @@ struct aa_stft_plan {
     std::vector<float> window_host;
     float *d_window = nullptr;
     FftTables tabs;
-    // wave1024 path
+    // wave-per-frame paths (n_fft 1024 / 2048)
+    bool wave2048 = false;
     bool wave1024 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
@@ -460,6 +492,20 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)kMelSlab * n_mels));
             }
         }
+        if (cfg->n_fft == 2048 && cfg->hop % 64 == 0) {
+            int fpw = 4;
+            while (fpw > 1 && aa::wave2048_lds_dwords(fpw, cfg->hop) > 16384)
+                --fpw;
+            if (aa::wave2048_lds_dwords(fpw, cfg->hop) <= 16384) {
+                std::vector<float> tab;
+                build_wave2048_table(p->window_host.data(), &tab);
+                AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+                p->frames_per_wg = fpw;
+                p->wave2048 = true;
+            }
+        }
         if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
             // frames per workgroup chunk: the tunable default, shrunk until the LDS need fits 64 KiB.
             int fpw = 8;
@@ -518,6 +564,8 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "";
     if (p->wave1024)
         return "wave1024";
+    if (p->wave2048)
+        return "wave2048";
     return p->tabs.pow2 ? "lds_radix2" : "dft";
 }
 
@@ -548,6 +596,9 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         const float *first = samples_dev + fb * (int64_t)p->cfg.hop;
         if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                       p->frames_per_wg, p->log_floor, st));
+        } else if (p->wave2048 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+            AA_HIP(aa::launch_wave2048(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));
         } else {
             AA_HIP(aa::launch_generic_forward(p->tabs.pow2, kind, samples_dev, dst, p->d_window,

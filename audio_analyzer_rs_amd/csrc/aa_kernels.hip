@@ -591,6 +591,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
@@ -644,7 +645,22 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
 #pragma unroll
             for (int kk = 1; kk < 8; ++kk)
                 v[kk] = pk_cmul(v[kk], twB[kk]);
-            if (!(ABL & 2)) {
+            if (ABL & 128) {
+                // E2 through LDS as well: writer lane (k1 = l&7, b = l>>3) stores register ka at
+                // 66 k1 + 8 ka + b (the E1 write pointer), reader lane (k1 = L&7, ka = L>>3) loads
+                // b = 0..7 from 66 k1 + 8 ka (writes conflict free, b128 reads 2-way)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    e1_wr[8 * kk] = v[kk];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v4f qv = e2_rd[i];
+                    v[2 * i] = v2f{qv.x, qv.y};
+                    v[2 * i + 1] = v2f{qv.z, qv.w};
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (!(ABL & 2)) {
                 // the DPP / permlane moves read registers the packed asm just wrote: keep the
                 // two wait states the hazard rules ask for (the compiler cannot see into asm)
                 asm volatile("s_nop 1");
@@ -789,6 +805,229 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
         frames_left -= frames_per_wg;
     }
     AA_CLK_END
+}
+
+// ---------------------------------------------------- wave-per-frame, n_fft = 2048 --
+// The tuner geometry of the reference (window 2048, hop 512: src/audio_io/stft.rs:169-170).
+// 1024 complex points per frame = one radix-2 split over two 512-point transforms that one
+// wave runs interleaved with the 8 x 8 x 8 machinery of the 1024 kernel:
+//   z_even[n] = (x[4n], x[4n+1]), z_odd[n] = (x[4n+2], x[4n+3])  - one ds_read_b128 per lane
+//   E = FFT512(z_even), O = FFT512(z_odd)            (passes A / E1 / B / E2 / C, twice)
+//   Z[k] = E[k] + W_1024^k O[k],  Z[k+512] = E[k] - W_1024^k O[k]          (in-lane)
+//   X[k], X[1024-k] from Z[k], conj(Z[1024-k]) with -i W_2048^k; the upper half of Z crosses
+//   the wave-private LDS strip (8 ds_write_b64 + 8 ds_read_b64 per lane)
+// Staging (LDS-DMA double buffer), persistence, row staging and store scheme as in
+// stft_wave1024_v5_kernel.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
+// 32..45 W_512^(lane k), 46..59 W_64^((lane>>3) k), 60..75 W_1024^(lane+64kb),
+// 76..91 -i W_2048^(lane+64kb).
+__device__ __forceinline__ void fft512_pass_a(v2f (&v)[8], const v2f (&twA)[8])
+{
+    pk_dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        v[k] = pk_cmul(v[k], twA[k]);
+}
+__device__ __forceinline__ void fft512_exchange1(v2f (&v)[8], v2f *e1_wr, const v4f *e1_rd)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        e1_wr[8 * k] = v[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v4f qv = e1_rd[i];
+        v[2 * i] = v2f{qv.x, qv.y};
+        v[2 * i + 1] = v2f{qv.z, qv.w};
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
+{
+    pk_dft8(v);
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        v[k] = pk_cmul(v[k], twB[k]);
+    asm volatile("s_nop 1");   // packed asm -> DPP / permlane read hazard (see the 1024 kernel)
+    exchange_high(v);
+    pk_dft8(v);
+}
+
+template <int OUT, bool WIDE>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave2048_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
+    float log_floor)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
+    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    const int max_span = (frames_per_wg - 1) * hop + 2048;
+    v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
+    constexpr int NB = 1025;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+    const int64_t first_frame = (int64_t)c0 * frames_per_wg;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;
+    float *out_chunk = out + first_frame * COLS;
+    int frames_left = (int)(n_frames - first_frame);
+    const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
+
+    auto stage = [&](const float *src, int nfc, int which) {
+        const int span4 = ((nfc - 1) * hop + 2048) >> 2;
+        float *dst = smem + which * max_span;
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+            const int q = qb + lane;
+            if (q < span4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + 4 * q),
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+        }
+    };
+    if (c0 < c1)
+        stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
+
+    v4f win[8];
+    v2f twA[8], twB[8], wc[8], tws[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
+                     tab[(4 * j + 3) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
+        twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wc[j] = v2f{tab[(60 + 2 * j) * 64 + lane], tab[(61 + 2 * j) * 64 + lane]};
+        tws[j] = v2f{tab[(76 + 2 * j) * 64 + lane], tab[(77 + 2 * j) * 64 + lane]};
+    }
+
+    v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);
+    const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+
+    for (int c = c0; c < c1; ++c) {
+        const int cur = (c - c0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        if (c + 1 < c1) {
+            const int nleft = frames_left - frames_per_wg;
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+        }
+        const int row0 = (c * frames_per_wg) & 31;
+        const v4f *buf = reinterpret_cast<const v4f *>(smem + cur * max_span) + lane;
+
+        for (int t = wave; t < nf; t += 4) {
+            const v4f *fr = buf + ((t * hop) >> 2);
+            v2f e[8], o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v4f sx = fr[64 * j] * win[j];
+                e[j] = v2f{sx.x, sx.y};
+                o[j] = v2f{sx.z, sx.w};
+            }
+            fft512_pass_a(e, twA);
+            fft512_exchange1(e, e1_wr, e1_rd);
+            fft512_pass_a(o, twA);
+            fft512_exchange1(o, e1_wr, e1_rd);
+            fft512_pass_bc(e, twB);
+            fft512_pass_bc(o, twB);
+            // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
+            v2f zl[8], zh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v2f tt = pk_cmul(o[j], wc[j]);
+                zl[j] = e[j] + tt;
+                zh[j] = e[j] - tt;
+            }
+            // strip[i] = Z[512 + i], i = 0..511; strip[512] = Z[1024] := Z[0]
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                scr[lane + 64 * j] = zh[j];
+            if (lane == 0)
+                scr[512] = zl[0];
+            __builtin_amdgcn_wave_barrier();
+            v2f prt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                prt[j] = scr[512 - (lane + 64 * j)];
+            __builtin_amdgcn_wave_barrier();
+
+            float *row = out_chunk + t * COLS;
+            v2f xk[8], xm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v2f ee = pk_add_conj(zl[j], prt[j]), oo = pk_sub_conj(zl[j], prt[j]);
+                v2f tt = pk_cmul(oo, tws[j]);
+                xk[j] = ee + tt;
+                xm[j] = ee - tt;                       // X[1024-k] = conj(xm)
+            }
+            const v2f z512 = zh[0];                    // lane 0: Z[512]; X[512] = 2 conj(Z[512])
+            if (OUT == kComplex) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = lane + 64 * j;
+                    reinterpret_cast<v2f *>(row)[k] = xk[j];
+                    reinterpret_cast<v2f *>(row)[1024 - k] = v2f{xm[j].x, -xm[j].y};
+                }
+                if (lane == 0)
+                    reinterpret_cast<v2f *>(row)[512] = v2f{2.0f * z512.x, -2.0f * z512.y};
+            } else {
+                float mk[8], mm[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
+                    mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+                }
+                const float m512 = bin_value<OUT>(2.0f * z512.x, 2.0f * z512.y, log_floor);
+                if (WIDE) {
+                    const int sh = (row0 + t) & 3;     // 1025 = 1 (mod 4): same shift rule as 513
+                    float *lrow = reinterpret_cast<float *>(scr) + sh;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        lrow[lane + 64 * j] = mk[j];
+                        lrow[1024 - lane - 64 * j] = mm[j];
+                    }
+                    if (lane == 0)
+                        lrow[512] = m512;
+                    __builtin_amdgcn_wave_barrier();
+                    const float *lw = reinterpret_cast<const float *>(scr);
+                    float *gw = row - sh;
+                    // window floats 4..1023 as 4 dwordx4 pieces (the last one 63 lanes), head
+                    // floats sh..3 and tail floats 1024..1024+sh by single dwords
+#pragma unroll
+                    for (int pce = 0; pce < 4; ++pce) {
+                        const int ls = (pce == 3 && lane == 63) ? 62 : lane;   // keep the last read in range
+                        v4f bb = *reinterpret_cast<const v4f *>(lw + 4 + 256 * pce + 4 * ls);
+                        if (pce < 3 || lane < 63)
+                            __builtin_nontemporal_store(bb, reinterpret_cast<v4f *>(gw + 4 + 256 * pce + 4 * lane));
+                    }
+                    const int hi = lane < 4 ? lane : 1020 + lane;
+                    const float hv = lw[lane < 8 ? hi : 0];
+                    const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
+                    if (ok)
+                        gw[hi] = hv;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        row[lane + 64 * j] = mk[j];
+                        row[1024 - lane - 64 * j] = mm[j];
+                    }
+                    if (lane == 0)
+                        row[512] = m512;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        src_chunk += src_stride;
+        out_chunk += out_stride;
+        frames_left -= frames_per_wg;
+    }
 }
 
 // ------------------------------------------------------- generic forward paths --
@@ -1082,6 +1321,50 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     case kLogPower:
         return launch_wave1024_kind<kLogPower>(packed, wide, x, out, table, frame_begin, n_frames, hop,
                                                frames_per_wg, log_floor, stream);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int K>
+static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, const float *table,
+                                       int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                                       float log_floor, hipStream_t stream)
+{
+    const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
+    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop);
+    static int cached_grid = 0;
+    static size_t cached_lds = 0;
+    if (cached_grid == 0 || cached_lds != lds) {
+        cached_grid = persistent_grid(stft_wave2048_kernel<K, true>, lds);
+        cached_lds = lds;
+    }
+    const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
+    if (wide)
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+    else
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
+                           int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                           float log_floor, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    switch (out_kind) {
+    case kComplex:
+        return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kMag:
+        return launch_wave2048_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kPower:
+        return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kLogPower:
+        return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     default:
         return hipErrorInvalidValue;
     }

@@ -54,7 +54,9 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 def test_kernel_selection(aa):
     assert aa.Stft(1024, 256).kernel == "wave1024"
     assert aa.Stft(1024, 100).kernel == "lds_radix2"     # hop not a multiple of 64
-    assert aa.Stft(2048, 512).kernel == "lds_radix2"
+    assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
+    assert aa.Stft(2048, 500).kernel == "lds_radix2"
+    assert aa.Stft(256, 64).kernel == "lds_radix2"          # onset geometry (onset.rs:122-123)
     assert aa.Stft(1000, 250).kernel == "dft"
 
 
@@ -90,6 +92,39 @@ def test_wave1024_hops(aa, oracle_mod, torch_mod, hop):
     ref = oracle_mod.stft(x, n, hop, kind="mag")
     assert got.shape == ref.shape
     assert nerr(got, ref.astype(np.float64)).max() < TOL_VS_ORACLE
+
+
+@pytest.mark.parametrize("n_frames", [1, 2, 3, 4, 5, 7, 8, 9, 33, 1000])
+@pytest.mark.parametrize("output", ["mag", "complex"])
+def test_wave2048_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
+    """The tuner geometry (2048 / 512, src/audio_io/stft.rs:169-170) on its own kernel."""
+    n, hop = 2048, 512
+    rng = np.random.default_rng(100 + n_frames)
+    L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
+    x = (0.5 * rng.standard_normal(L)).astype(np.float32)
+    plan = aa.Stft(n, hop, output=output)
+    assert plan.kernel == "wave2048"
+    got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle_mod.stft(x, n, hop, kind=output)
+    tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
+    tru = tru if output == "complex" else np.abs(tru)
+    assert got.shape == ref.shape == (n_frames, 1025)
+    assert nerr(got, ref.astype(tru.dtype)).max() < TOL_VS_ORACLE
+    assert nerr(got, tru).max() < TOL_VS_TRUTH
+
+
+@pytest.mark.parametrize("hop", [64, 512, 1024, 2048])
+def test_wave2048_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
+    n = 2048
+    x = aa.signals.synth_corpus(999, n + 50 * hop + 3)
+    w = oracle_mod.hann_window(n)
+    P = np.abs(oracle_mod.truth.stft_complex(x, n, hop, w)) ** 2
+    xd = torch_mod.from_numpy(x).cuda()
+    plan = aa.Stft(n, hop, output="power")
+    assert plan.kernel == "wave2048"
+    assert nerr(plan(xd).cpu().numpy(), P).max() < 2 * TOL_VS_TRUTH
+    part = aa.Stft(n, hop, output="mag").execute_device(xd, 3, 40).cpu().numpy()
+    assert nerr(part, np.sqrt(P[3:40])).max() < TOL_VS_TRUTH
 
 
 def test_wave1024_power_and_logpower(aa, oracle_mod, torch_mod):
@@ -129,7 +164,7 @@ def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
 
 # -------------------------------------------------------------------- generic paths --
 @pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 64), (512, 128),
-                                   (1024, 100), (2048, 512), (4096, 1024), (8192, 4096)])
+                                   (1024, 100), (2048, 500), (4096, 1024), (8192, 4096)])
 @pytest.mark.parametrize("output", ["mag", "complex"])
 def test_lds_radix2_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
     rng = np.random.default_rng(n + hop)

@@ -75,22 +75,11 @@ int main(int argc, char **argv)
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < 8; ++i) run<0>(fpw, "warm-up (ignore)");
-    run<0>(fpw, "full kernel");
-    run<256>(fpw, "stores hit 32 L2-resident rows");
-    run<1>(fpw, "no stores");
-    run<0>(fpw, "full kernel");
-    run<256>(fpw, "stores hit 32 L2-resident rows");
-    run<1>(fpw, "no stores");
-    for (int pc : {2, 4, 5}) run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only", pc);
-    for (int pc : {2, 4, 5}) run<1 | 8 | 32>(fpw, "no stores/DMA/barrier", pc);
-    run<1>(fpw, "no global stores");
-    run<2>(fpw, "no E2 (register exchange)");
-    run<4>(fpw, "no E1 (LDS exchange)");
-    run<8>(fpw, "no DMA after first chunk");
-    run<16>(fpw, "no split strip");
-    run<32>(fpw, "no per-chunk wait+barrier (+races)");
-    run<8 | 32>(fpw, "no DMA, no barrier");
-    run<2 | 4 | 16>(fpw, "no exchanges at all");
-    run<0>(fpw, "full kernel (again)");
+    run<0>(fpw, "full kernel, E2 in registers");
+    run<128>(fpw, "full kernel, E2 through LDS");
+    run<0>(fpw, "full kernel, E2 in registers");
+    run<128>(fpw, "full kernel, E2 through LDS");
+    run<1|8|32>(fpw, "compute only, E2 regs");
+    run<1|8|32|128>(fpw, "compute only, E2 LDS");
     return 0;
 }
