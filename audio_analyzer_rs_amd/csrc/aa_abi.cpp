@@ -212,6 +212,42 @@ void build_wave2048_table(const float *window, std::vector<float> *tab)
     }
 }
 
+// Per-lane constants of the 256-point kernel, [kWave256Rows][64] (row meaning in
+// aa_kernels.hip above stft_wave256_kernel).  q = lane & 15 is the lane within its frame.
+void build_wave256_table(const float *window, std::vector<float> *tab)
+{
+    tab->assign((size_t)aa::kWave256Rows * 64, 0.0f);
+    float *T = tab->data();
+    for (int lane = 0; lane < 64; ++lane) {
+        const int q = lane & 15;
+        for (int j = 0; j < 8; ++j)
+            for (int c = 0; c < 2; ++c)
+                T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (16 * j + q) + c];
+        for (int k = 1; k < 8; ++k) {
+            double a = -2.0 * kPi * (double)(q * k) / 128.0;
+            T[(16 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
+            T[(17 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
+        }
+        const int dist[4] = {8, 4, 2, 1};
+        for (int s = 0; s < 4; ++s) {
+            const int d = dist[s];
+            const bool upper = (q & d) != 0;
+            T[(36 + s) * 64 + lane] = upper ? -1.0f : 1.0f;
+            if (s < 3) {
+                double a = upper ? -2.0 * kPi * (double)(q % d) / (2.0 * d) : 0.0;
+                T[(30 + 2 * s) * 64 + lane] = (float)std::cos(a);
+                T[(31 + 2 * s) * 64 + lane] = (float)std::sin(a);
+            }
+        }
+        for (int i = 0; i < 5; ++i) {
+            const int kk = (lane + 64 * i) % 65;
+            double th = 2.0 * kPi * (double)kk / 256.0;
+            T[(40 + 2 * i) * 64 + lane] = (float)(-std::sin(th));
+            T[(41 + 2 * i) * 64 + lane] = (float)(-std::cos(th));
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- plan structs --
@@ -234,6 +270,7 @@ struct aa_stft_plan {
     // wave-per-frame paths (n_fft 1024 / 2048)
     bool wave2048 = false;
     bool wave1024 = false;
+    bool wave256 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
     // mel / MFCC post-ops (build-defined)
@@ -492,6 +529,21 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)kMelSlab * n_mels));
             }
         }
+        if (cfg->n_fft == 256 && cfg->hop % 4 == 0 && cfg->hop % 2 == 0) {
+            // chunk = 32 frames (8 groups of 4, two per wave); shrink in steps of 16 to fit 64 KiB
+            int fpw = 32;
+            while (fpw > 16 && aa::wave256_lds_dwords(fpw, cfg->hop) > 16384)
+                fpw -= 16;
+            if (aa::wave256_lds_dwords(fpw, cfg->hop) <= 16384) {
+                std::vector<float> tab;
+                build_wave256_table(p->window_host.data(), &tab);
+                AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+                p->frames_per_wg = fpw;
+                p->wave256 = true;
+            }
+        }
         if (cfg->n_fft == 2048 && cfg->hop % 64 == 0) {
             int fpw = 4;
             while (fpw > 1 && aa::wave2048_lds_dwords(fpw, cfg->hop) > 16384)
@@ -566,6 +618,8 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "wave1024";
     if (p->wave2048)
         return "wave2048";
+    if (p->wave256)
+        return "wave256";
     return p->tabs.pow2 ? "lds_radix2" : "dft";
 }
 
@@ -597,6 +651,9 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));
+        } else if (p->wave256 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+            AA_HIP(aa::launch_wave256(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                      p->frames_per_wg, p->log_floor, st));
         } else if (p->wave2048 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave2048(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));

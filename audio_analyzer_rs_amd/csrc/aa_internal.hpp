@@ -57,6 +57,21 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream);
 
+// ---- wave-per-4-frames 256-point kernel (onset geometry) ---------------------------
+constexpr int kWave256Rows = 50;
+inline int64_t wave256_lds_dwords(int frames_per_wg, int hop)
+{
+    const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 256;
+    return 2 * span + 4 * kWave1024ScratchDwords;
+}
+inline size_t wave256_lds_bytes(int frames_per_wg, int hop)
+{
+    return sizeof(float) * (size_t)wave256_lds_dwords(frames_per_wg, hop);
+}
+hipError_t launch_wave256(int out_kind, const float *x, float *out, const float *table,
+                          int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                          float log_floor, hipStream_t stream);
+
 // ---- generic kernels (any even length) ---------------------------------------
 // Frame t reads x[t*hop + i] * window[i] (window may be null).  Rows of
 // out: kComplex -> 2*(n/2+1) floats, else n/2+1 floats.

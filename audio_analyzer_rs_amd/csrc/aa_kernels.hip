@@ -247,6 +247,15 @@ __device__ __forceinline__ void exchange_high(float2 (&v)[8])
     }
 }
 
+// The packed-math asm is invisible to hipcc's hazard recogniser: a VALU write followed by a
+// DPP / permlane read of the same VGPR needs two wait states.  Tying the registers to the
+// nop keeps every producer before it and every cross-lane consumer after it.
+__device__ __forceinline__ void hazard_fence(v2f (&v)[8])
+{
+    asm volatile("s_nop 1"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
 // same exchange on packed values (vector elements are not addressable: go through floats)
 __device__ __forceinline__ void xpose_pk(v2f &a, v2f &b, int stage)
 {
@@ -661,9 +670,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
                 }
                 __builtin_amdgcn_wave_barrier();
             } else if (!(ABL & 2)) {
-                // the DPP / permlane moves read registers the packed asm just wrote: keep the
-                // two wait states the hazard rules ask for (the compiler cannot see into asm)
-                asm volatile("s_nop 1");
+                hazard_fence(v);   // packed asm -> DPP / permlane read
                 exchange_high(v);
             }
             pk_dft8(v);
@@ -847,7 +854,7 @@ __device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
 #pragma unroll
     for (int k = 1; k < 8; ++k)
         v[k] = pk_cmul(v[k], twB[k]);
-    asm volatile("s_nop 1");   // packed asm -> DPP / permlane read hazard (see the 1024 kernel)
+    hazard_fence(v);   // packed asm -> DPP / permlane read
     exchange_high(v);
     pk_dft8(v);
 }
@@ -1020,6 +1027,226 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave2048_kernel(
                     }
                     if (lane == 0)
                         row[512] = m512;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        src_chunk += src_stride;
+        out_chunk += out_stride;
+        frames_left -= frames_per_wg;
+    }
+}
+
+// ----------------------------------------------------- wave-per-4-frames, n_fft = 256 --
+// The onset geometry of the reference (window 256, hop 64: src/analysis/onset.rs:122-123).
+// 128 complex points per frame: 16 lanes per frame (one DPP row), 8 points per lane, so one
+// wave transforms FOUR consecutive frames at once:
+//   pass A   radix-8 over j in registers (lane q reads m = 16 j + q), x W_128^(q k1)
+//   16-point radix-2 DIF across the 16 lanes of a row, for all 8 registers at once: partner
+//            via DPP (row_ror:8, row_shl/shr:4 with bank masks, quad_perm), butterfly as one
+//            packed fma  y = sigma x + partner  (sigma = -1 on the upper lane), stage twiddle
+//   -> lane q holds Z[k1 + 8 bitrev4(q)]
+//   split    Z of the 4 frames goes to a wave-private LDS strip (4 x ds_write_b128 per lane);
+//            260 (k, 128-k) pairs are spread over the 64 lanes (5 per lane), each pair yields
+//            X[k] and X[128-k]; magnitudes land in a dense 4-row LDS image
+//   store    4 rows x 129 floats = 129 float4: rows 4g..4g+3 start 16-byte aligned, so the
+//            image leaves as 3 nontemporal dwordx4 stores per FOUR frames.
+// Table rows ([50][64]): 0..15 0.5*w[2(16j+q)+c] (row 2j+c), 16..29 W_128^(q k1) k1=1..7,
+// 30..35 DIF stage twiddles (d = 8, 4, 2), 36..39 sigma per stage, 40..49 -i W_256^k of the
+// lane's five pairs (k = (lane + 64 i) % 65).
+constexpr int kW256StripStride = 130;   // complex per frame in the strip (129 + 1: 16-B aligned rows)
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ v2f dpp_pair(v2f old, v2f src)
+{
+    return v2f{dpp_update<CTRL, BANK_MASK>(old.x, src.x), dpp_update<CTRL, BANK_MASK>(old.y, src.y)};
+}
+template <int OUT, bool WIDE>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
+    float log_floor)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fq = lane >> 4, q = lane & 15;           // frame-in-group, lane-in-frame
+
+    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
+    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    const int max_span = (frames_per_wg - 1) * hop + 256;
+    float *scrf = smem + 2 * max_span + wave * kWave1024ScratchDwords;
+    v2f *scr = reinterpret_cast<v2f *>(scrf);
+    constexpr int NB = 129;
+    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+    const int64_t first_frame = (int64_t)c0 * frames_per_wg;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;
+    float *out_chunk = out + first_frame * COLS;
+    int frames_left = (int)(n_frames - first_frame);
+    const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
+
+    auto stage = [&](const float *src, int nfc, int which) {
+        const int span4 = ((nfc - 1) * hop + 256) >> 2;
+        float *dst = smem + which * max_span;
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+            const int qq = qb + lane;
+            if (qq < span4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + 4 * qq),
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+        }
+    };
+    if (c0 < c1)
+        stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
+
+    v2f win[8], twA[8], wst[3], sig[4], tws[5];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        twA[k] = v2f{tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]};
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        wst[s] = v2f{tab[(30 + 2 * s) * 64 + lane], tab[(31 + 2 * s) * 64 + lane]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        sig[s] = v2f{tab[(36 + s) * 64 + lane], tab[(36 + s) * 64 + lane]};
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        tws[i] = v2f{tab[(40 + 2 * i) * 64 + lane], tab[(41 + 2 * i) * 64 + lane]};
+
+    // pair bookkeeping: pair p = lane + 64 i -> frame p / 65, bin k = p % 65
+    int pa[5], pb[5], rlo[5], rhi[5], pfr[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int p = lane + 64 * i;
+        const int fr = p / 65, k = p - 65 * fr;
+        pfr[i] = p < 260 ? fr : 4;                     // 4 = no such pair
+        pa[i] = (fr & 3) * kW256StripStride + k;
+        pb[i] = (fr & 3) * kW256StripStride + 128 - k;
+        rlo[i] = (fr & 3) * NB + k;
+        rhi[i] = (fr & 3) * NB + 128 - k;
+    }
+    const int br = ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3);
+    v4f *strip_wr = reinterpret_cast<v4f *>(scr + fq * kW256StripStride + 8 * br);
+    const unsigned smem_addr = lds_addr(smem);
+
+    for (int c = c0; c < c1; ++c) {
+        const int cur = (c - c0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        if (c + 1 < c1) {
+            const int nleft = frames_left - frames_per_wg;
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+        }
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * q);
+
+        for (int g = wave; 4 * g < nf; g += 4) {
+            const int t = 4 * g + fq;                  // this lane's frame within the chunk
+            const int nvalid = nf - 4 * g < 4 ? nf - 4 * g : 4;
+            // a lane of a frame past the end reads the last valid frame instead (stays in the
+            // staged span); its results are never stored
+            const int tr = t < nf ? t : nf - 1;
+            const unsigned fr = buf_addr + 4u * (unsigned)(tr * hop);
+            v2f v[8];
+            v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<128>(fr); v[2] = lds_read_b64<256>(fr);
+            v[3] = lds_read_b64<384>(fr); v[4] = lds_read_b64<512>(fr); v[5] = lds_read_b64<640>(fr);
+            v[6] = lds_read_b64<768>(fr); v[7] = lds_read_b64<896>(fr);
+            lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = v[j] * win[j];
+            pk_dft8(v);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                v[k] = pk_cmul(v[k], twA[k]);
+
+            // ---- 16-point DIF across the row ----
+            hazard_fence(v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {              // d = 8
+                v2f p = dpp_pair<0x128, 0xF>(v[k], v[k]);
+                v[k] = pk_cmul(v[k] * sig[0] + p, wst[0]);
+            }
+            hazard_fence(v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {              // d = 4: lanes 0-3,8-11 take lane+4, others lane-4
+                v2f p = dpp_pair<0x104, 0x5>(v[k], v[k]);       // row_shl:4 -> lane + 4
+                p = dpp_pair<0x114, 0xA>(p, v[k]);              // row_shr:4 -> lane - 4
+                v[k] = pk_cmul(v[k] * sig[1] + p, wst[1]);
+            }
+            hazard_fence(v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {              // d = 2
+                v2f p = dpp_pair<0x4E, 0xF>(v[k], v[k]);
+                v[k] = pk_cmul(v[k] * sig[2] + p, wst[2]);
+            }
+            hazard_fence(v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {              // d = 1 (no twiddle)
+                v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);
+                v[k] = v[k] * sig[3] + p;
+            }
+            // lane q now holds Z[k1 + 8 bitrev4(q)], k1 = 0..7 of its frame
+
+            // ---- strip: Z of the four frames, Z[128] := Z[0] ----
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                strip_wr[i] = v4f{v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y};
+            if (q == 0)
+                scr[fq * kW256StripStride + 128] = v[0];
+            __builtin_amdgcn_wave_barrier();
+            v2f za[5], zb[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                za[i] = scr[pa[i]];
+                zb[i] = scr[pb[i]];
+            }
+            __builtin_amdgcn_wave_barrier();
+            float *grp = out_chunk + (4 * g) * COLS;   // first row of the group
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                v2f e = pk_add_conj(za[i], zb[i]), o = pk_sub_conj(za[i], zb[i]);
+                v2f tt = pk_cmul(o, tws[i]);
+                v2f xk = e + tt, xm = e - tt;          // X[128-k] = conj(xm)
+                const bool live = pfr[i] < nvalid;
+                if (OUT == kComplex) {
+                    if (live) {
+                        reinterpret_cast<v2f *>(grp)[rlo[i]] = xk;
+                        reinterpret_cast<v2f *>(grp)[rhi[i]] = v2f{xm.x, -xm.y};
+                    }
+                } else {
+                    const float mk = bin_value<OUT>(xk.x, xk.y, log_floor);
+                    const float mm = bin_value<OUT>(xm.x, xm.y, log_floor);
+                    if (pfr[i] < 4) {
+                        scrf[rlo[i]] = mk;
+                        scrf[rhi[i]] = mm;
+                    }
+                }
+            }
+            if (OUT != kComplex) {
+                __builtin_amdgcn_wave_barrier();
+                if (WIDE && nvalid == 4) {
+                    // 516 floats = 129 float4, group start 16-byte aligned
+                    v4f b0 = *reinterpret_cast<const v4f *>(scrf + 4 * lane);
+                    v4f b1 = *reinterpret_cast<const v4f *>(scrf + 256 + 4 * lane);
+                    v4f b2 = *reinterpret_cast<const v4f *>(scrf + 512);
+                    __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(grp + 4 * lane));
+                    __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(grp + 256 + 4 * lane));
+                    if (lane == 0)
+                        __builtin_nontemporal_store(b2, reinterpret_cast<v4f *>(grp + 512));
+                } else {
+                    const int nfl = NB * nvalid;
+#pragma unroll
+                    for (int u = 0; u < 9; ++u) {
+                        const int idx = lane + 64 * u;
+                        if (idx < nfl)
+                            grp[idx] = scrf[idx];
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1365,6 +1592,50 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
         return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kLogPower:
         return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int K>
+static hipError_t launch_wave256_kind(bool wide, const float *x, float *out, const float *table,
+                                      int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                                      float log_floor, hipStream_t stream)
+{
+    const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
+    const size_t lds = wave256_lds_bytes(frames_per_wg, hop);
+    static int cached_grid = 0;
+    static size_t cached_lds = 0;
+    if (cached_grid == 0 || cached_lds != lds) {
+        cached_grid = persistent_grid(stft_wave256_kernel<K, true>, lds);
+        cached_lds = lds;
+    }
+    const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
+    if (wide)
+        hipLaunchKernelGGL((stft_wave256_kernel<K, true>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+    else
+        hipLaunchKernelGGL((stft_wave256_kernel<K, false>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_wave256(int out_kind, const float *x, float *out, const float *table,
+                          int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                          float log_floor, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    switch (out_kind) {
+    case kComplex:
+        return launch_wave256_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kMag:
+        return launch_wave256_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kPower:
+        return launch_wave256_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    case kLogPower:
+        return launch_wave256_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     default:
         return hipErrorInvalidValue;
     }
