@@ -144,7 +144,7 @@ void build_wave1024_table(const float *window, std::vector<float> *tab)
     }
 }
 
-constexpr int64_t kMelSlab = 8192;   // frames per power-spectrogram slab (stays L2/MALL resident)
+constexpr int64_t kMelSlab = 32768;  // frames per power-spectrogram slab (<= 134 MB: Infinity-Cache resident; 256 GEMM workgroups)
 
 // Slaney mel scale (linear below 1 kHz, log above) — the build's definition of AA_OUT_LOGMEL
 // (the reference has no mel stage); oracle/truth.py holds the float64 twin.
@@ -277,7 +277,9 @@ struct aa_stft_plan {
     int n_mels = 0, n_mels_pad = 0, n_mfcc = 0;
     float *d_melT = nullptr;       // [n_bins_pad x n_mels_pad]
     int *d_tile_k = nullptr;       // [n_mels_pad/32][2]
-    float *d_dct = nullptr;        // [n_mfcc x n_mels]
+    float *d_dct = nullptr;        // DCT-II matrix transposed, [n_mels_pad32 x n_mfcc_pad]
+    int *d_dct_tile_k = nullptr;   // full K range per 32-coefficient tile
+    int n_mfcc_pad = 0;
     float *d_ws_power = nullptr;   // [kMelSlab x n_bins]
     float *d_ws_logmel = nullptr;  // [kMelSlab x n_mels]
     // host-execute workspace
@@ -484,7 +486,9 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             return r;
         if (mel_out) {
             const int n_mels = cfg->n_mels, n_mels_pad = (n_mels + 31) / 32 * 32;
-            const int nb_pad = (nb + 63) / 64 * 64;
+            const int nb_pad = (nb + 31) / 32 * 32;
+            if (n_mels_pad > 128)
+                return fail(AA_ERR_UNSUPPORTED, "n_mels > 128 is not built (got %d)", n_mels);
             const double fmax = cfg->fmax > 0.0f ? cfg->fmax : cfg->sample_rate / 2.0;
             std::vector<double> w;
             mel_filterbank(cfg->sample_rate, cfg->n_fft, n_mels, cfg->fmin, fmax, &w);
@@ -500,8 +504,8 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                         }
                 if (hi <= lo)
                     lo = hi = 0;
-                tile_k[2 * t] = lo / 64 * 64;
-                tile_k[2 * t + 1] = (hi + 63) / 64 * 64;
+                tile_k[2 * t] = lo / 32 * 32;
+                tile_k[2 * t + 1] = (hi + 31) / 32 * 32;
             }
             for (int m = 0; m < n_mels; ++m)
                 for (int k = 0; k < nb; ++k)
@@ -515,17 +519,27 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             AA_HIP(hipMemcpy(p->d_tile_k, tile_k.data(), tile_k.size() * sizeof(int), hipMemcpyHostToDevice));
             AA_HIP(hipMalloc(&p->d_ws_power, sizeof(float) * (size_t)kMelSlab * nb));
             if (cfg->output == AA_OUT_MFCC) {
-                // DCT-II, orthonormal: d[c][m] = s_c cos(pi c (2m+1) / (2M)), s_0 = sqrt(1/M), else sqrt(2/M)
-                std::vector<float> dct((size_t)cfg->n_mfcc * n_mels);
+                // DCT-II, orthonormal: d[c][m] = s_c cos(pi c (2m+1) / (2M)), s_0 = sqrt(1/M), else
+                // sqrt(2/M); stored transposed [m][c] (B operand of the GEMM), zero padded
+                const int n_mfcc_pad = (cfg->n_mfcc + 31) / 32 * 32;
+                std::vector<float> dct((size_t)n_mels_pad * n_mfcc_pad, 0.0f);
                 for (int c = 0; c < cfg->n_mfcc; ++c)
                     for (int m = 0; m < n_mels; ++m) {
                         double v = std::cos(kPi * c * (2.0 * m + 1.0) / (2.0 * n_mels)) * std::sqrt(2.0 / n_mels);
                         if (c == 0)
                             v *= std::sqrt(0.5);
-                        dct[(size_t)c * n_mels + m] = (float)v;
+                        dct[(size_t)m * n_mfcc_pad + c] = (float)v;
                     }
+                std::vector<int> dtk(2 * (n_mfcc_pad / 32));
+                for (int t = 0; t < n_mfcc_pad / 32; ++t) {
+                    dtk[2 * t] = 0;
+                    dtk[2 * t + 1] = n_mels_pad;
+                }
+                p->n_mfcc_pad = n_mfcc_pad;
                 AA_HIP(hipMalloc(&p->d_dct, dct.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_dct, dct.data(), dct.size() * sizeof(float), hipMemcpyHostToDevice));
+                AA_HIP(hipMalloc(&p->d_dct_tile_k, dtk.size() * sizeof(int)));
+                AA_HIP(hipMemcpy(p->d_dct_tile_k, dtk.data(), dtk.size() * sizeof(int), hipMemcpyHostToDevice));
                 AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)kMelSlab * n_mels));
             }
         }
@@ -593,7 +607,8 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
     DeviceGuard g(p->device);
     free_fft_tables(&p->tabs);
     float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct,
-                     p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k)};
+                     p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
+                     reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -675,11 +690,12 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         if (rc != AA_OK)
             return rc;
         float *mel_dst = p->cfg.output == AA_OUT_MFCC ? p->d_ws_logmel : out_dev + f * p->n_mels;
-        AA_HIP(aa::launch_mel(true, p->d_ws_power, p->d_melT, p->d_tile_k, mel_dst, n, nb, p->n_mels,
-                              p->n_mels_pad, p->log_floor, st));
+        AA_HIP(aa::launch_rows_gemm(true, p->d_ws_power, nb, p->d_melT, p->d_tile_k, mel_dst, n, nb,
+                                    p->n_mels, p->n_mels_pad, p->log_floor, st));
         if (p->cfg.output == AA_OUT_MFCC)
-            AA_HIP(aa::launch_dct_rows(p->d_ws_logmel, p->d_dct, out_dev + f * p->n_mfcc, n, p->n_mels,
-                                       p->n_mfcc, st));
+            AA_HIP(aa::launch_rows_gemm(false, p->d_ws_logmel, p->n_mels, p->d_dct, p->d_dct_tile_k,
+                                        out_dev + f * p->n_mfcc, n, p->n_mels, p->n_mfcc, p->n_mfcc_pad,
+                                        0.0f, st));
     }
     return AA_OK;
 }

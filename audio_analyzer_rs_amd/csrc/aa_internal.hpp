@@ -87,13 +87,12 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
                                   const float *tw_split, int n, int64_t batch, hipStream_t stream);
 
 // ---- build-defined post-ops (aa_mel.hip) ----------------------------------------
-// melT: [n_bins_pad x n_mels_pad] (transposed, zero padded: bins to a multiple of 64, mels to
-// a multiple of 32); tile_k: int pairs [k_lo, k_hi) per 32-mel tile, multiples of 64.
-hipError_t launch_mel(bool take_log, const float *power, const float *melT, const int *tile_k,
-                      float *out, int64_t n_frames, int n_bins, int n_mels, int n_mels_pad,
-                      float log_floor, hipStream_t stream);
-hipError_t launch_dct_rows(const float *logmel, const float *dct, float *out, int64_t n_frames,
-                           int n_mels, int n_mfcc, hipStream_t stream);
+// C[n_rows x n_cols] = op(A[n_rows x K] . B): B is [k_pad x n_pad] row-major, zero padded
+// (k_pad % 32 == 0, n_pad % 32 == 0, n_pad <= 128); tile_k: int pairs [k_lo, k_hi) per 32-column
+// tile (multiples of 32); op = 10*log10(max(., floor)) when take_log.
+hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
+                            float *C, int64_t n_rows, int K, int n_cols, int n_pad, float log_floor,
+                            hipStream_t stream);
 hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int channels,
                           hipStream_t stream);
 

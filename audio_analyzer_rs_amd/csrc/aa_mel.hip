@@ -5,8 +5,8 @@
 //           (v_mfma_f32_32x32x2_f32: exact f32 fma chain — bf16/f16 inputs would break the
 //           1e-5 budget), skipping the K range where a 32-mel column tile is all zero
 //           (triangular filters: each tile touches a narrow band of bins);
-//   log     10*log10(max(mel, floor));
-//   DCT-II  orthonormal, [n_mels -> n_mfcc], one row per workgroup.
+//   log     10*log10(max(mel, floor)) in the GEMM epilogue;
+//   DCT-II  orthonormal, [n_mels -> n_mfcc]: the same GEMM kernel with the DCT matrix as B.
 // Also the stereo -> mono average of the capture callback (src/audio_io/mod.rs:784-794).
 #include "aa_internal.hpp"
 
@@ -15,100 +15,109 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMelKChunk = 64;          // bins staged per LDS round
-constexpr int kMelRows = 32;            // frames per workgroup
-constexpr int kMelLdA = kMelKChunk + 1; // +1: lanes of one MFMA operand read 32 rows, same k
+constexpr int kGemmK = 32;              // bins staged per LDS round
+constexpr int kGemmRows = 128;          // frames per workgroup (32 per wave)
+constexpr int kGemmLdA = kGemmK + 1;    // +1: the 32 rows one MFMA operand reads sit on 32 banks
 
-// power: [n_frames x n_bins] row-major.  melT: [n_bins_pad x n_mels_pad] row-major (filter
-// weights transposed, zero padded to a multiple of 32 mels and of kMelKChunk bins).
-// tile_k: per 32-mel column tile, [k_lo, k_hi) bin range that holds its non-zeros
-// (multiples of kMelKChunk).  out: [n_frames x n_mels].
-// Workgroup = 256 threads = 4 waves = 32 frames x 128 mels (one 32x32 tile per wave);
-// grid.y walks further groups of 128 mels.
+// C[F x n_cols] = op(A[F x K] . B[K x n_cols]) on the f32 matrix cores, B zero padded to
+// [k_pad x n_pad] (k_pad % 32 == 0, n_pad % 32 == 0).  tile_k holds, per 32-column tile of B,
+// the [k_lo, k_hi) range outside of which the tile is all zero (multiples of 32): triangular
+// mel filters touch a narrow band of bins, so most (tile, K-chunk) pairs are skipped.
+// Workgroup = 4 waves = 128 rows x (n_pad <= 128) columns; wave w owns rows 32w..32w+31 and one
+// 32x32 accumulator per column tile.  Exact f32: the MFMA is a k-ordered fmaf chain.
 template <bool LOG>
-__global__ __launch_bounds__(256) void mel_mfma_kernel(const float *__restrict__ power,
-                                                       const float *__restrict__ melT,
-                                                       const int2 *__restrict__ tile_k,
-                                                       float *__restrict__ out, int64_t n_frames,
-                                                       int n_bins, int n_mels, int n_mels_pad,
-                                                       float log_floor)
+__global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float *__restrict__ A, int lda,
+                                                             const float *__restrict__ B,
+                                                             const int2 *__restrict__ tile_k,
+                                                             float *__restrict__ C, int64_t n_rows,
+                                                             int K, int n_cols, int n_pad,
+                                                             float log_floor)
 {
-    __shared__ float As[kMelRows * kMelLdA];
-    __shared__ float Bs[kMelKChunk * 128];
+    __shared__ float As[kGemmRows * kGemmLdA];
+    __shared__ float Bs[kGemmK * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * kMelRows;
-    const int col0 = blockIdx.y * 128;
-    const int tile = blockIdx.y * 4 + wave;
-    // the workgroup walks the union of its four tiles' K ranges
+    const int64_t row0 = (int64_t)blockIdx.x * kGemmRows;
+    const int n_tiles = n_pad >> 5;                       // <= 4
+    int2 rng[4];
     int k_lo = 1 << 30, k_hi = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (col0 + 32 * w < n_mels_pad) {
-            int2 r = tile_k[blockIdx.y * 4 + w];
-            k_lo = r.x < k_lo ? r.x : k_lo;
-            k_hi = r.y > k_hi ? r.y : k_hi;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        rng[c] = c < n_tiles ? tile_k[c] : make_int2(0, 0);
+        if (c < n_tiles && rng[c].y > rng[c].x) {
+            k_lo = rng[c].x < k_lo ? rng[c].x : k_lo;
+            k_hi = rng[c].y > k_hi ? rng[c].y : k_hi;
         }
     }
-    const bool wave_active = col0 + 32 * wave < n_mels_pad;
-    const int2 my = wave_active ? tile_k[tile] : make_int2(0, 0);
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int ai = lane & 31, ak = lane >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ai = lane & 31, ah = lane >> 5;
+    const float *a_row = As + (32 * wave + ai) * kGemmLdA + ah;
+    const float *b_col = Bs + ah * 128 + ai;
 
-    for (int kb = k_lo; kb < k_hi; kb += kMelKChunk) {
-        // stage A: 32 rows x 64 bins (coalesced along bins)
-        for (int e = tid; e < kMelRows * kMelKChunk; e += 256) {
-            const int r = e >> 6, k = e & 63;
+    // Software pipeline: the global loads of chunk i+1 are issued before the MFMAs of chunk i
+    // and land in registers (16 + 16 VGPRs); one LDS write + barrier pair per chunk.
+    float ra[16];
+    float4 rb[4];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            const int r = e >> 5, k = e & 31;
             const int64_t gr = row0 + r;
-            const int gk = kb + k;
-            As[r * kMelLdA + k] = (gr < n_frames && gk < n_bins) ? power[gr * n_bins + gk] : 0.0f;
+            ra[u] = (gr < n_rows && kb + k < K) ? A[gr * lda + kb + k] : 0.0f;
         }
-        // stage B: 64 bins x 128 mels
-        for (int e = tid; e < kMelKChunk * 128; e += 256) {
-            const int k = e >> 7, c = e & 127;
-            Bs[e] = (col0 + c < n_mels_pad) ? melT[(int64_t)(kb + k) * n_mels_pad + col0 + c] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            const int k = e >> 5, c4 = e & 31;
+            rb[u] = (4 * c4 < n_pad) ? *reinterpret_cast<const float4 *>(B + (int64_t)(kb + k) * n_pad + 4 * c4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (k_lo < k_hi)
+        fetch(k_lo);
+    for (int kb = k_lo; kb < k_hi; kb += kGemmK) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            As[(e >> 5) * kGemmLdA + (e & 31)] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<float4 *>(Bs + (e >> 5) * 128 + 4 * (e & 31)) = rb[u];
         }
         __syncthreads();
-        if (wave_active && kb + kMelKChunk > my.x && kb < my.y) {
-#pragma unroll 8
-            for (int k = 0; k < kMelKChunk; k += 2) {
-                const float a = As[ai * kMelLdA + k + ak];
-                const float b = Bs[(k + ak) * 128 + 32 * wave + ai];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        if (kb + kGemmK < k_hi)
+            fetch(kb + kGemmK);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < n_tiles && kb + kGemmK > rng[c].x && kb < rng[c].y) {
+#pragma unroll
+                for (int k = 0; k < kGemmK; k += 2)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_row[k], b_col[k * 128 + 32 * c], acc[c], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    if (!wave_active)
-        return;
     // C/D layout of the 32x32 f32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int col = col0 + 32 * wave + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (gr < n_frames && col < n_mels) {
-            float v = acc[r];
-            if (LOG)
-                v = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(v, log_floor));
-            out[gr * n_mels + col] = v;
+    for (int c = 0; c < 4; ++c) {
+        const int col = 32 * c + ai;
+        if (c >= n_tiles || col >= n_cols)
+            continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t gr = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * ah;
+            if (gr < n_rows) {
+                float v = acc[c][r];
+                if (LOG)
+                    v = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(v, log_floor));
+                C[gr * n_cols + col] = v;
+            }
         }
-    }
-}
-
-// MFCC: out[f][c] = sum_m dct[c][m] * logmel[f][m]; one frame per 64-thread workgroup.
-__global__ __launch_bounds__(64) void dct_rows_kernel(const float *__restrict__ logmel,
-                                                      const float *__restrict__ dct,
-                                                      float *__restrict__ out, int n_mels,
-                                                      int n_mfcc)
-{
-    extern __shared__ float row[];
-    const int64_t f = blockIdx.x;
-    for (int m = threadIdx.x; m < n_mels; m += 64)
-        row[m] = logmel[f * n_mels + m];
-    __syncthreads();
-    for (int c = threadIdx.x; c < n_mfcc; c += 64) {
-        float s = 0.0f;
-        for (int m = 0; m < n_mels; ++m)
-            s = fmaf(dct[c * n_mels + m], row[m], s);
-        out[f * n_mfcc + c] = s;
     }
 }
 
@@ -128,30 +137,22 @@ __global__ void downmix_kernel(const float *__restrict__ in, float *__restrict__
 
 }  // namespace
 
-hipError_t launch_mel(bool take_log, const float *power, const float *melT, const int *tile_k,
-                      float *out, int64_t n_frames, int n_bins, int n_mels, int n_mels_pad,
-                      float log_floor, hipStream_t stream)
+hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
+                            float *C, int64_t n_rows, int K, int n_cols, int n_pad, float log_floor,
+                            hipStream_t stream)
 {
-    if (n_frames <= 0)
+    if (n_rows <= 0)
         return hipSuccess;
-    dim3 grid((unsigned)((n_frames + kMelRows - 1) / kMelRows), (unsigned)((n_mels_pad + 127) / 128));
+    if (n_pad > 128 || (n_pad & 31))
+        return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_rows + kGemmRows - 1) / kGemmRows));
     const int2 *tk = reinterpret_cast<const int2 *>(tile_k);
     if (take_log)
-        hipLaunchKernelGGL(mel_mfma_kernel<true>, grid, dim3(256), 0, stream, power, melT, tk, out,
-                           n_frames, n_bins, n_mels, n_mels_pad, log_floor);
+        hipLaunchKernelGGL(rows_gemm_mfma_kernel<true>, grid, dim3(256), 0, stream, A, lda, B, tk, C, n_rows,
+                           K, n_cols, n_pad, log_floor);
     else
-        hipLaunchKernelGGL(mel_mfma_kernel<false>, grid, dim3(256), 0, stream, power, melT, tk, out,
-                           n_frames, n_bins, n_mels, n_mels_pad, log_floor);
-    return hipGetLastError();
-}
-
-hipError_t launch_dct_rows(const float *logmel, const float *dct, float *out, int64_t n_frames,
-                           int n_mels, int n_mfcc, hipStream_t stream)
-{
-    if (n_frames <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(dct_rows_kernel, dim3((unsigned)n_frames), dim3(64), sizeof(float) * n_mels,
-                       stream, logmel, dct, out, n_mels, n_mfcc);
+        hipLaunchKernelGGL(rows_gemm_mfma_kernel<false>, grid, dim3(256), 0, stream, A, lda, B, tk, C, n_rows,
+                           K, n_cols, n_pad, log_floor);
     return hipGetLastError();
 }
 

@@ -265,12 +265,12 @@ def test_logmel_two_channels(aa, oracle_mod, torch_mod, n, hop):
         assert nerr(10.0 ** (got.astype(np.float64) / 10.0), np.maximum(M, 1e-10)).max() < 2e-5
         near = L >= L.max(axis=1, keepdims=True) - 40.0
         assert np.max(np.abs(got - L)[near]) < 1e-3
-    # host path and slab boundary (more than one 8192-frame slab)
-    x = aa.signals.synth_corpus(7, n + 8500 * hop)
+    # host path and slab boundary (more than one 32768-frame slab)
+    x = aa.signals.synth_corpus(7, n + 33000 * hop)
     got = plan(x)
-    _, L = _logmel_truth(oracle_mod, x[(8190 * hop):], n, hop, sr, n_mels)
+    _, L = _logmel_truth(oracle_mod, x[(32760 * hop):], n, hop, sr, n_mels)
     near = L >= L.max(axis=1, keepdims=True) - 40.0
-    assert np.max(np.abs(got[8190:] - L)[near]) < 1e-3
+    assert np.max(np.abs(got[32760:] - L)[near]) < 1e-3
 
 
 def test_mfcc_sine_and_chirp(aa, oracle_mod, torch_mod):
