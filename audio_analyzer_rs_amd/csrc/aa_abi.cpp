@@ -282,7 +282,9 @@ struct aa_stft_plan {
     int n_mfcc_pad = 0;
     float *d_ws_power = nullptr;   // [kMelSlab x n_bins]
     float *d_ws_logmel = nullptr;  // [kMelSlab x n_mels]
-    // host-execute workspace
+    // host-execute workspace and the two-stream pipeline used for page-locked host buffers
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t pipe_event = nullptr;
     float *d_ws_in = nullptr;
     size_t ws_in_floats = 0;
     float *d_ws_out = nullptr;
@@ -606,6 +608,11 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
         return AA_OK;
     DeviceGuard g(p->device);
     free_fft_tables(&p->tabs);
+    for (hipStream_t st : p->pipe_stream)
+        if (st)
+            (void)hipStreamDestroy(st);
+    if (p->pipe_event)
+        (void)hipEventDestroy(p->pipe_event);
     float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
@@ -700,6 +707,16 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
     return AA_OK;
 }
 
+static bool is_pinned_host(const void *ptr)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary pageable memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 static int grow(float **buf, size_t *have, size_t want)
 {
     if (*have >= want)
@@ -730,14 +747,63 @@ int aa_stft_execute_host(aa_stft_plan *p, const float *samples_host, int64_t n_s
     rc = grow(&p->d_ws_out, &p->ws_out_floats, (size_t)nf * p->out_cols);
     if (rc != AA_OK)
         return rc;
+    const size_t row_bytes = sizeof(float) * (size_t)p->out_cols;
+    const bool fft_only = p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC;
+    const int64_t chunk = 16384;   // frames per pipeline stage
+    if (fft_only && nf >= 2 * chunk && is_pinned_host(samples_host) && is_pinned_host(out_host)) {
+        // Both buffers are page-locked (aa_host_register / hipHostMalloc): run H2D, kernel and
+        // D2H of consecutive frame chunks on two streams so the copy engines overlap compute.
+        for (int i = 0; i < 2; ++i)
+            if (!p->pipe_stream[i])
+                AA_HIP(hipStreamCreateWithFlags(&p->pipe_stream[i], hipStreamNonBlocking));
+        if (!p->pipe_event)
+            AA_HIP(hipEventCreateWithFlags(&p->pipe_event, hipEventDisableTiming));
+        int64_t copied = 0;   // samples [0, copied) are on the device or in flight
+        int k = 0;
+        for (int64_t f0 = 0; f0 < nf; f0 += chunk, ++k) {
+            const int64_t f1 = std::min(nf, f0 + chunk);
+            const int64_t need = (f1 - 1) * (int64_t)p->cfg.hop + p->cfg.n_fft;
+            hipStream_t st = p->pipe_stream[k & 1];
+            if (k > 0)   // the halo of this chunk was copied by the previous chunk's stream
+                AA_HIP(hipStreamWaitEvent(st, p->pipe_event, 0));
+            AA_HIP(hipMemcpyAsync(p->d_ws_in + copied, samples_host + copied,
+                                  sizeof(float) * (size_t)(need - copied), hipMemcpyHostToDevice, st));
+            copied = need;
+            AA_HIP(hipEventRecord(p->pipe_event, st));
+            rc = aa_stft_execute_device(p, p->d_ws_in, n_samples, f0, f1, p->d_ws_out + f0 * p->out_cols, st);
+            if (rc != AA_OK)
+                return rc;
+            AA_HIP(hipMemcpyAsync(out_host + f0 * p->out_cols, p->d_ws_out + f0 * p->out_cols,
+                                  row_bytes * (size_t)(f1 - f0), hipMemcpyDeviceToHost, st));
+        }
+        AA_HIP(hipStreamSynchronize(p->pipe_stream[0]));
+        AA_HIP(hipStreamSynchronize(p->pipe_stream[1]));
+        return AA_OK;
+    }
     AA_HIP(hipMemcpyAsync(p->d_ws_in, samples_host, sizeof(float) * (size_t)n_samples,
                           hipMemcpyHostToDevice, nullptr));
     rc = aa_stft_execute_device(p, p->d_ws_in, n_samples, 0, nf, p->d_ws_out, nullptr);
     if (rc != AA_OK)
         return rc;
-    AA_HIP(hipMemcpyAsync(out_host, p->d_ws_out, sizeof(float) * (size_t)nf * p->out_cols,
-                          hipMemcpyDeviceToHost, nullptr));
+    AA_HIP(hipMemcpyAsync(out_host, p->d_ws_out, row_bytes * (size_t)nf, hipMemcpyDeviceToHost, nullptr));
     AA_HIP(hipStreamSynchronize(nullptr));
+    return AA_OK;
+}
+
+// Page-lock a caller buffer so aa_stft_execute_host can stream it at PCIe rate.
+int aa_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0)
+        return fail(AA_ERR_ARG, "aa_host_register: bad argument");
+    AA_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return AA_OK;
+}
+
+int aa_host_unregister(void *ptr)
+{
+    if (!ptr)
+        return fail(AA_ERR_ARG, "aa_host_unregister: NULL");
+    AA_HIP(hipHostUnregister(ptr));
     return AA_OK;
 }
 

@@ -65,12 +65,15 @@ class Stft:
             return self.execute_host(samples)
         return self.execute_device(samples, frame_begin, frame_end, out, stream)
 
-    def execute_host(self, samples):
+    def execute_host(self, samples, out=None):
         x = np.ascontiguousarray(samples, dtype=np.float32)
         if x.ndim != 1:
             raise _lib.AaError(_lib.AA_ERR_ARG, "samples must be one-dimensional (mono)")
         nf = self.num_frames(x.shape[0])
-        out = np.empty((nf, self.cols), dtype=np.float32)
+        if out is None:
+            out = np.empty((nf, self.cols), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (nf, self.cols) or not out.flags.c_contiguous:
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"out must be C-contiguous float32 [{nf}, {self.cols}]")
         if nf:
             _lib.check(self._lib.aa_stft_execute_host(self._plan, _lib.f32_ptr(x), x.shape[0],
                                                       _lib.f32_ptr(out)))
@@ -98,6 +101,19 @@ class Stft:
         if self.output == "complex":
             return torch.view_as_complex(out.view(-1, self.cols // 2, 2))
         return out
+
+
+def pin(array):
+    """Page-lock a numpy array in place (aa_host_register).  With both the samples and the output
+    array pinned, `Stft.execute_host` overlaps H2D, kernels and D2H on two streams."""
+    lib = _lib.load()
+    _lib.check(lib.aa_host_register(array.ctypes.data, array.nbytes))
+    return array
+
+
+def unpin(array):
+    lib = _lib.load()
+    _lib.check(lib.aa_host_unregister(array.ctypes.data))
 
 
 def downmix(interleaved, channels, stream=None):

@@ -152,6 +152,13 @@ int aa_stft_execute_device(aa_stft_plan *plan, const float *samples_dev, int64_t
 int aa_stft_execute_host(aa_stft_plan *plan, const float *samples_host, int64_t n_samples,
                          float *out_host);
 
+/* Page-lock / release a caller-owned host buffer (hipHostRegister).  With BOTH buffers of
+ * aa_stft_execute_host registered, the call streams frame chunks over two HIP streams (H2D,
+ * kernel, D2H overlapped) instead of staging through pageable copies.  The caller must
+ * unregister before freeing the memory. */
+int aa_host_register(void *ptr, size_t bytes);
+int aa_host_unregister(void *ptr);
+
 /* ---- capture-side downmix (src/audio_io/mod.rs:784-794) -------------------- */
 /* mono[i] = (sum of the first min(channels, 2) channels of frame i) / that count: what the
  * input callback does before a slot reaches the STFT workers (the reference never runs a

@@ -364,6 +364,56 @@ def test_short_inputs(aa, torch_mod):
     assert plan(torch_mod.zeros(1000, device="cuda")).shape == (0, 513)
 
 
+# ------------------------------------------------------------- streams and hipGraphs --
+def test_execute_on_side_stream_and_graph_replay(aa, oracle_mod, torch_mod):
+    """The launch path does no allocation or synchronisation, so it can run on any stream
+    and be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
+    n, hop = 1024, 256
+    x = aa.signals.synth_corpus(42, n + 999 * hop)
+    ref = oracle_mod.stft(x, n, hop, kind="mag")
+    xd = torch_mod.from_numpy(x).cuda()
+    plan = aa.Stft(n, hop, output="mag")
+    out = torch_mod.zeros((1000, 513), device="cuda")
+    plan.execute_device(xd, out=out)                        # first call sizes the persistent grid
+    torch_mod.cuda.synchronize()
+    side = torch_mod.cuda.Stream()
+    out.zero_()
+    side.wait_stream(torch_mod.cuda.current_stream())
+    with torch_mod.cuda.stream(side):
+        plan.execute_device(xd, out=out, stream=side.cuda_stream)
+    side.synchronize()
+    assert nerr(out.cpu().numpy(), ref.astype(np.float64)).max() < TOL_VS_ORACLE
+    # capture + replay on new input data written into the same device buffer
+    g = torch_mod.cuda.CUDAGraph()
+    out.zero_()
+    with torch_mod.cuda.graph(g):
+        plan.execute_device(xd, out=out, stream=torch_mod.cuda.current_stream().cuda_stream)
+    x2 = aa.signals.synth_corpus(4242, n + 999 * hop)
+    xd.copy_(torch_mod.from_numpy(x2))
+    g.replay()
+    torch_mod.cuda.synchronize()
+    ref2 = oracle_mod.stft(x2, n, hop, kind="mag")
+    assert nerr(out.cpu().numpy(), ref2.astype(np.float64)).max() < TOL_VS_ORACLE
+
+
+def test_pinned_host_pipeline_matches_plain_host_path(aa, torch_mod):
+    """aa_host_register'ed buffers take the two-stream chunked path; rows must equal the plain
+    staged path bit for bit (same kernels, same frame indexing)."""
+    n, hop = 1024, 256
+    x = aa.signals.synth_corpus(5, n + 40_000 * hop + 17)
+    plan = aa.Stft(n, hop, output="mag")
+    plain = plan.execute_host(x)
+    out = np.empty_like(plain)
+    aa.pin(x)
+    aa.pin(out)
+    try:
+        got = plan.execute_host(x, out=out)
+    finally:
+        aa.unpin(out)
+        aa.unpin(x)
+    assert got is out and np.array_equal(got, plain)
+
+
 # ------------------------------------------------------------------- streaming front --
 @pytest.mark.parametrize("n,hop,ring", [(2048, 512, 8192), (256, 64, 4096), (1024, 256, 0)])
 def test_stream_matches_oracle_stream(aa, oracle_mod, n, hop, ring):
