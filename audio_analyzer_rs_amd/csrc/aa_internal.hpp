@@ -16,16 +16,6 @@ enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3 };
 constexpr int kWave1024Rows = 52;
 constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
-// Kernel variant: 5 (default) = packed-f32 complex arithmetic; 3 = its scalar twin.
-// AA_W1024_VARIANT=3 overrides (A/B runs only).
-inline int wave1024_variant()
-{
-    static const int v = [] {
-        const char *s = std::getenv("AA_W1024_VARIANT");
-        return (s && s[0] == '3') ? 3 : 5;
-    }();
-    return v;
-}
 // LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
 // of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
 inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop)

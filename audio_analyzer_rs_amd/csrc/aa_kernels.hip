@@ -13,29 +13,6 @@
 namespace aa {
 namespace {
 
-// In-kernel phase stamps (diagnostic builds only: tools/stamp_w1024.hip defines AA_STAMPS;
-// the shipped library never executes a stamp).  acc[i] += cycles since the previous stamp.
-#ifdef AA_STAMPS
-#define AA_STAMP_DECL unsigned long long st_prev_ = 0, st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define AA_STAMP(i)                                                                          \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        unsigned long long t_;                                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
-        st_acc_[i] += t_ - st_prev_;                                                         \
-        st_prev_ = t_;                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#define AA_STAMP_DUMP(dbg)                                                                   \
-    if (lane == 0)                                                                           \
-        for (int i_ = 0; i_ < 12; ++i_)                                                      \
-            (dbg)[((size_t)blockIdx.x * 4 + wave) * 12 + i_] = st_acc_[i_];
-#else
-#define AA_STAMP_DECL
-#define AA_STAMP(i)
-#define AA_STAMP_DUMP(dbg)
-#endif
-
 // Clock probe for tools/ablate_w1024.hip (diagnostic builds only): shader cycles and
 // 100 MHz real-time ticks spent by each workgroup's wave 0.
 #ifdef AA_ABLATE
@@ -88,8 +65,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w)
 {
     return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
 }
-// a * (-i)
-__device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
 
 template <int OUT>
 __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
@@ -101,28 +76,6 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
-}
-
-// 8-point DFT over the register index, natural order in and out (radix-2 DIF,
-// the bit-reversal is a compile-time renaming).
-__device__ __forceinline__ void dft8(float2 (&v)[8])
-{
-    const float h = 0.70710678118654752440f;
-    float2 a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
-    float2 a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
-    float2 a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
-    b1 = make_float2((b1.x + b1.y) * h, (b1.y - b1.x) * h);   // * W8^1
-    b2 = cmul_mi(b2);                                         // * W8^2
-    b3 = make_float2((b3.y - b3.x) * h, -(b3.x + b3.y) * h);  // * W8^3
-    float2 c0 = cadd(a0, a2), c2 = csub(a0, a2);
-    float2 c1 = cadd(a1, a3), c3 = cmul_mi(csub(a1, a3));
-    float2 d0 = cadd(b0, b2), d2 = csub(b0, b2);
-    float2 d1 = cadd(b1, b3), d3 = cmul_mi(csub(b1, b3));
-    v[0] = cadd(c0, c1); v[4] = csub(c0, c1);
-    v[2] = cadd(c2, c3); v[6] = csub(c2, c3);
-    v[1] = cadd(d0, d1); v[5] = csub(d0, d1);
-    v[3] = cadd(d2, d3); v[7] = csub(d2, d3);
 }
 
 // ---- packed-f32 complex arithmetic ------------------------------------------------
@@ -225,28 +178,6 @@ __device__ __forceinline__ void xpose_pair_b5(float &ri, float &rj)
     rj = __uint_as_float(r[1]);
 }
 
-// register bits 0,1,2 <-> lane bits 3,4,5
-__device__ __forceinline__ void exchange_high(float2 (&v)[8])
-{
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {   // p = 0 <-> lane bit 3
-        xpose_pair_b3(v[i].x, v[i + 1].x);
-        xpose_pair_b3(v[i].y, v[i + 1].y);
-    }
-#pragma unroll
-    for (int g = 0; g < 8; g += 4)     // p = 1 <-> lane bit 4
-#pragma unroll
-        for (int i = g; i < g + 2; ++i) {
-            xpose_pair_b4(v[i].x, v[i + 2].x);
-            xpose_pair_b4(v[i].y, v[i + 2].y);
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {      // p = 2 <-> lane bit 5
-        xpose_pair_b5(v[i].x, v[i + 4].x);
-        xpose_pair_b5(v[i].y, v[i + 4].y);
-    }
-}
-
 // The packed-math asm is invisible to hipcc's hazard recogniser: a VALU write followed by a
 // DPP / permlane read of the same VGPR needs two wait states.  Tying the registers to the
 // nop keeps every producer before it and every cross-lane consumer after it.
@@ -288,259 +219,28 @@ __device__ __forceinline__ void exchange_high(v2f (&v)[8])
         xpose_pk(v[i], v[i + 4], 2);
 }
 
-// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 3 --
-// Persistent, software-pipelined kernel with scalar f32 arithmetic (the packed variant 5
-// below is the shipped default; this one is its A/B twin, AA_W1024_VARIANT=3):
-//   * a workgroup owns a contiguous run of chunks (frames_per_wg frames each) and loops
-//     over them; the per-lane constant table is loaded once per workgroup, not per chunk;
-//   * the samples of chunk c+1 are fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
-//     into the other half of a double buffer while chunk c is transformed;
-//   * staging is unpadded (DMA writes 1 KiB contiguous per wave instruction): pass A uses
-//     the natural mapping lane = n2 (m = 64 j + lane), conflict-free for ds_read_b64;
-//   * E1 scratch addressing for that mapping: writer lane (a = l>>3, b = l&7) stores Y[k1]
-//     at complex 66 b + 8 k1 + a, reader lane (k1 = L&7, b = L>>3) loads 8 consecutive
-//     complex from 66 b + 8 k1 (4 x ds_read_b128); both sides are bank-conflict free.
-
-// ABL: ablation mask for tools/ablate_w1024.hip (diagnostic; 0 in the shipped library):
-//   1 no global stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split strip,
-//   32 no per-chunk barrier/vmcnt wait
+// ---------------------------------------------------- wave-per-frame, n_fft = 1024 --
+// One wavefront transforms one frame: the 1024 windowed reals are read as 512 complex points
+// z[m] (8 per lane), 512 = 8 x 8 x 8:
+//   pass A  radix-8 over j (lane reads m = 64 j + lane from the staged samples), x W_512^(lane k1)
+//   E1      registers <-> lanes through a wave-private LDS scratch: writer lane (a = l>>3,
+//           b = l&7) stores Y[k1] at complex 66 b + 8 k1 + a (ds_write_b64), reader lane
+//           (k1 = L&7, b = L>>3) loads 8 consecutive complex from 66 b + 8 k1 (4 x
+//           ds_read_b128); the skew 66 keeps both sides bank-conflict free
+//   pass B  radix-8 over a, x W_64^(b ka)
+//   E2      registers <-> lane bits 3-5 in registers: v_mov_b32_dpp row_ror:8 with bank masks,
+//           v_permlane16_swap, v_permlane32_swap (no select: v_cndmask_b32 costs 12-19 cycles)
+//   pass C  radix-8 over b -> lane L holds Z[L + 64 kb]
+//   split   X[k], X[512-k] from Z[k], conj(Z[512-k]); the partner half crosses the scratch
+//   store   |X| row staged in the scratch at its 16-byte-aligned window, nontemporal dwordx4
+// A persistent workgroup (4 waves) owns a contiguous run of 8-frame chunks; chunk c+1 arrives by
+// LDS-DMA (global_load_lds_dwordx4) in the other half of a double buffer while chunk c is
+// transformed; each wave interleaves its two frames of the chunk.  All complex arithmetic is
+// packed f32 (pk_* helpers above).  ABL is the ablation mask of tools/ablate_w1024.hip (0 in the
+// shipped library): 1 no stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split
+// strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines.
 template <int OUT, int ABL = 0, bool WIDE = false>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v3_kernel(
-    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
-    int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor
-#ifdef AA_STAMPS
-    , unsigned long long *dbg
-#endif
-    )
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int64_t c0 = (int64_t)blockIdx.x * n_chunks / gridDim.x;
-    const int64_t c1 = (int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x;
-    const int max_span = (frames_per_wg - 1) * hop + 1024;          // floats, multiple of 64
-    float2 *scr = reinterpret_cast<float2 *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
-
-    // LDS-DMA of one chunk's samples into buffer `which` (wave w moves 1 KiB pieces w, w+4, ..)
-    auto stage = [&](int64_t c, int which) {
-        const int64_t f0 = c * frames_per_wg;
-        const int64_t left = n_frames - f0;
-        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
-        const int span4 = ((nf - 1) * hop + 1024) >> 2;
-        const float *src = x + (frame_begin + f0) * (int64_t)hop;
-        float *dst = smem + which * max_span;
-        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
-            const int q = qb + lane;
-            if (q < span4)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + 4 * (int64_t)q),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
-        }
-    };
-
-    if (c0 < c1)
-        stage(c0, 0);
-
-    float win[16];
-    float2 twA[8], twB[8], tws[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        win[i] = tab[i * 64 + lane];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        twA[k] = make_float2(tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]);
-        twB[k] = make_float2(tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        tws[j] = make_float2(tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]);
-
-    const unsigned smem_addr = lds_addr(smem);
-    float2 *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
-    const float4 *e1_rd = reinterpret_cast<const float4 *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
-
-    AA_STAMP_DECL
-    AA_STAMP(0);   // 0: prologue (first DMA issue + table loads)
-    for (int64_t c = c0; c < c1; ++c) {
-        const int cur = (int)(c - c0) & 1;
-        // chunk c has landed (this wave's DMA) and every wave is done with chunk c-1
-        if (!(ABL & 32) || c == c0) {
-            // vmcnt retires in issue order and counts stores: the DMA of chunk c is older than
-            // every row store of chunk c-1 (9 per frame), so waiting down to that many
-            // outstanding operations covers the DMA without waiting for the store acks.
-            if ((ABL & 64) || c == c0 || frames_per_wg != 8)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            AA_STAMP(1);   // 1: vmcnt wait (DMA of this chunk)
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
-        }
-        AA_STAMP(2);   // 2: barrier
-        if (c + 1 < c1 && !(ABL & 8))
-            stage(c + 1, cur ^ 1);
-        AA_STAMP(3);   // 3: DMA issue
-
-        const int64_t f0 = c * frames_per_wg;
-        const int64_t left = n_frames - f0;
-        const int nf = left < frames_per_wg ? (int)left : frames_per_wg;
-        const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
-
-        for (int t = wave; t < nf; t += 4) {
-            const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
-            float2 v[8];
-            {
-                v2f s0 = lds_read_b64<0>(fr), s1 = lds_read_b64<512>(fr), s2 = lds_read_b64<1024>(fr),
-                    s3 = lds_read_b64<1536>(fr), s4 = lds_read_b64<2048>(fr), s5 = lds_read_b64<2560>(fr),
-                    s6 = lds_read_b64<3072>(fr), s7 = lds_read_b64<3584>(fr);
-                lds_wait_8(s0, s1, s2, s3, s4, s5, s6, s7);
-                AA_STAMP(4);   // 4: frame ds_read_b64 x8 + wait
-                v[0] = make_float2(s0.x * win[0], s0.y * win[1]);
-                v[1] = make_float2(s1.x * win[2], s1.y * win[3]);
-                v[2] = make_float2(s2.x * win[4], s2.y * win[5]);
-                v[3] = make_float2(s3.x * win[6], s3.y * win[7]);
-                v[4] = make_float2(s4.x * win[8], s4.y * win[9]);
-                v[5] = make_float2(s5.x * win[10], s5.y * win[11]);
-                v[6] = make_float2(s6.x * win[12], s6.y * win[13]);
-                v[7] = make_float2(s7.x * win[14], s7.y * win[15]);
-            }
-            dft8(v);
-#pragma unroll
-            for (int k = 1; k < 8; ++k)
-                v[k] = cmul(v[k], twA[k]);
-            AA_STAMP(5);   // 5: window + pass A + twiddle
-            // ---- E1 through LDS ----
-            if (!(ABL & 4)) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    e1_wr[8 * k] = v[k];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float4 qv = e1_rd[i];
-                    v[2 * i] = make_float2(qv.x, qv.y);
-                    v[2 * i + 1] = make_float2(qv.z, qv.w);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            AA_STAMP(6);   // 6: E1 writes + reads + wait
-            dft8(v);
-#pragma unroll
-            for (int k = 1; k < 8; ++k)
-                v[k] = cmul(v[k], twB[k]);
-            AA_STAMP(7);   // 7: pass B + twiddle
-            if (!(ABL & 2))
-                exchange_high(v);
-            AA_STAMP(8);   // 8: E2 (DPP + permlane swaps)
-            dft8(v);
-            AA_STAMP(9);   // 9: pass C
-
-            // ---- split ----
-            float2 prt[4];
-            if (!(ABL & 16)) {
-#pragma unroll
-                for (int j = 4; j < 8; ++j)
-                    scr[lane + 64 * (j - 4)] = v[j];
-                if (lane == 0)
-                    scr[256] = v[0];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    prt[j] = scr[256 - (lane + 64 * j)];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    prt[j] = v[7 - j];
-            }
-            float *row = out + (f0 + t) * (int64_t)COLS;
-            AA_STAMP(10);  // 10: split strip writes + reads + wait
-            if (WIDE && OUT != kComplex && !(ABL & 1)) {
-                // Row through LDS so it leaves as 16-byte-aligned nontemporal dwordx4 stores:
-                // on gfx950 this R:W mix moves 6.2 TB/s that way against 4.5-4.7 TB/s with
-                // plain dword or dwordx4 stores (tools/ubench_rw2.hip).  The row starts at
-                // float 513 r of a 16-byte-aligned buffer, so its aligned window begins
-                // sh = r & 3 floats earlier; LDS float i <-> global float 513 r - sh + i.
-                const int sh = (int)((f0 + t) & 3);
-                float *lrow = reinterpret_cast<float *>(scr) + sh;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + 64 * j;
-                    float2 a = v[j];
-                    float2 p = prt[j];
-                    float2 bc = make_float2(p.x, -p.y);
-                    float2 e = cadd(a, bc), o = csub(a, bc);
-                    float2 tt = cmul(o, tws[j]);
-                    float2 xk = cadd(e, tt);
-                    float2 xm = csub(e, tt);
-                    lrow[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
-                    lrow[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
-                }
-                if (lane == 0)
-                    lrow[256] = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
-                __builtin_amdgcn_wave_barrier();
-                const float *lw = reinterpret_cast<const float *>(scr);
-                float *gw = row - sh;                                   // 16-byte aligned
-                v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
-                __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
-                if (lane < 63) {
-                    v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * lane);
-                    __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                }
-                // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
-                const int hi = lane < 4 ? lane : 508 + lane;
-                const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
-                if (ok)
-                    gw[hi] = lw[hi];
-            } else {
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = lane + 64 * j;
-                    float2 a = v[j];
-                    float2 p = prt[j];
-                    float2 bc = make_float2(p.x, -p.y);
-                    float2 e = cadd(a, bc), o = csub(a, bc);
-                    float2 tt = cmul(o, tws[j]);
-                    float2 xk = cadd(e, tt);
-                    float2 xm = csub(e, tt);
-                    if (ABL & 1) {
-                        float r0 = bin_value<OUT>(xk.x, xk.y, log_floor), r1 = bin_value<OUT>(xm.x, xm.y, log_floor);
-                        asm volatile("" ::"v"(r0), "v"(r1));
-                    } else if (OUT == kComplex) {
-                        reinterpret_cast<float2 *>(row)[k] = xk;
-                        reinterpret_cast<float2 *>(row)[512 - k] = make_float2(xm.x, -xm.y);
-                    } else {
-                        row[k] = bin_value<OUT>(xk.x, xk.y, log_floor);
-                        row[512 - k] = bin_value<OUT>(xm.x, xm.y, log_floor);
-                    }
-                }
-                if (lane == 0 && !(ABL & 1)) {
-                    float2 z = v[4];
-                    if (OUT == kComplex)
-                        reinterpret_cast<float2 *>(row)[256] = make_float2(2.0f * z.x, -2.0f * z.y);
-                    else
-                        row[256] = bin_value<OUT>(2.0f * z.x, 2.0f * z.y, log_floor);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            AA_STAMP(11);  // 11: split math + magnitude + stores
-        }
-    }
-    AA_STAMP_DUMP(dbg)
-}
-
-// ------------------------------------------ wave-per-frame, n_fft = 1024, variant 5 --
-// Variant 3 (persistent, LDS-DMA double buffer, E1 through LDS, aligned nontemporal row
-// stores) with every complex operation on packed f32 (pk_* helpers above).  Occupancy
-// sweeps of the ablated kernel showed the compute side saturating the VALU (~2.8 cycles
-// per scalar op in situ): packing halves the instruction count of the butterflies,
-// twiddles and the split.
-template <int OUT, int ABL = 0, bool WIDE = false, bool TWO = true>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
     float log_floor)
@@ -600,7 +300,6 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
@@ -654,22 +353,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
 #pragma unroll
             for (int kk = 1; kk < 8; ++kk)
                 v[kk] = pk_cmul(v[kk], twB[kk]);
-            if (ABL & 128) {
-                // E2 through LDS as well: writer lane (k1 = l&7, b = l>>3) stores register ka at
-                // 66 k1 + 8 ka + b (the E1 write pointer), reader lane (k1 = L&7, ka = L>>3) loads
-                // b = 0..7 from 66 k1 + 8 ka (writes conflict free, b128 reads 2-way)
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    e1_wr[8 * kk] = v[kk];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v4f qv = e2_rd[i];
-                    v[2 * i] = v2f{qv.x, qv.y};
-                    v[2 * i + 1] = v2f{qv.z, qv.w};
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else if (!(ABL & 2)) {
+            if (!(ABL & 2)) {
                 hazard_fence(v);   // packed asm -> DPP / permlane read
                 exchange_high(v);
             }
@@ -771,7 +455,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
             }
         };
 
-        if (TWO && frames_per_wg == 8) {
+        if (frames_per_wg == 8) {
             // Two frames of this wave (t = wave and wave + 4) interleaved phase by phase: the
             // independent work of one frame fills the LDS round trips and VALU dependency stalls
             // of the other.  The single scratch area is safe: DS operations of a wave execute in
@@ -824,7 +508,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_v5_kernel(
 //   X[k], X[1024-k] from Z[k], conj(Z[1024-k]) with -i W_2048^k; the upper half of Z crosses
 //   the wave-private LDS strip (8 ds_write_b64 + 8 ds_read_b64 per lane)
 // Staging (LDS-DMA double buffer), persistence, row staging and store scheme as in
-// stft_wave1024_v5_kernel.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
+// stft_wave1024_kernel.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
 // 32..45 W_512^(lane k), 46..59 W_64^((lane>>3) k), 60..75 W_1024^(lane+64kb),
 // 76..91 -i W_2048^(lane+64kb).
 __device__ __forceinline__ void fft512_pass_a(v2f (&v)[8], const v2f (&twA)[8])
@@ -1460,7 +1144,7 @@ __global__ void irfft_kernel(const float *__restrict__ spec, float *__restrict__
 }  // namespace
 
 // ------------------------------------------------------------------- launchers --
-#if !defined(AA_STAMPS) && !defined(AA_ABLATE)   // diagnostic builds drive the kernels themselves
+#ifndef AA_ABLATE   // the diagnostic build (tools/ablate_w1024.hip) drives the kernel itself
 // Persistent grid: resident workgroups per CU (occupancy API) x CUs.  There is no
 // inter-workgroup dependency, so an over- or under-estimate only changes speed.
 template <typename K>
@@ -1479,46 +1163,25 @@ static int persistent_grid(K kernel, size_t lds)
 }
 
 template <int K>
-static hipError_t launch_wave1024_kind(bool packed, bool wide, const float *x, float *out,
-                                       const float *table, int64_t frame_begin, int64_t n_frames,
-                                       int hop, int frames_per_wg, float log_floor, hipStream_t stream)
+static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, const float *table,
+                                       int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                                       float log_floor, hipStream_t stream)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     const size_t lds = wave1024_lds_bytes(frames_per_wg, hop);
-    static int cached_grid[2] = {0, 0};
-    static size_t cached_lds[2] = {0, 0};
-    const int slot = packed ? 1 : 0;
-    if (cached_grid[slot] == 0 || cached_lds[slot] != lds) {
-        cached_grid[slot] = packed ? persistent_grid(stft_wave1024_v5_kernel<K, 0, true>, lds)
-                                   : persistent_grid(stft_wave1024_v3_kernel<K, 0, true>, lds);
-        cached_lds[slot] = lds;
+    static int cached_grid = 0;
+    static size_t cached_lds = 0;
+    if (cached_grid == 0 || cached_lds != lds) {
+        cached_grid = persistent_grid(stft_wave1024_kernel<K, 0, true>, lds);
+        cached_lds = lds;
     }
-    const dim3 grid((unsigned)(cached_grid[slot] < chunks ? cached_grid[slot] : chunks));
-    const dim3 block(kWave1024Threads);
-#define AA_GO(KERNEL, W)                                                                       \
-    hipLaunchKernelGGL((KERNEL<K, 0, W>), grid, block, lds, stream, x, out, table, frame_begin, \
-                       n_frames, hop, frames_per_wg, chunks, log_floor)
-    // AA_W1024_TWO=0: one frame at a time per wave (A/B runs only)
-    static const bool two_env = [] {
-        const char *e = std::getenv("AA_W1024_TWO");
-        return !(e && e[0] == '0');
-    }();
-    if (packed && !two_env) {
-        if (wide)
-            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, true, false>), grid, block, lds, stream, x, out,
-                               table, frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
-        else
-            hipLaunchKernelGGL((stft_wave1024_v5_kernel<K, 0, false, false>), grid, block, lds, stream, x, out,
-                               table, frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
-    } else if (packed && wide)
-        AA_GO(stft_wave1024_v5_kernel, true);
-    else if (packed)
-        AA_GO(stft_wave1024_v5_kernel, false);
-    else if (wide)
-        AA_GO(stft_wave1024_v3_kernel, true);
+    const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
+    if (wide)
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, true>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
     else
-        AA_GO(stft_wave1024_v3_kernel, false);
-#undef AA_GO
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
     return hipGetLastError();
 }
 
@@ -1528,26 +1191,17 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
 {
     if (n_frames <= 0)
         return hipSuccess;
-    const bool packed = wave1024_variant() == 5;
-    // aligned nontemporal row stores need a 16-byte-aligned output buffer (AA_W1024_WIDE=0: A/B)
-    static const bool wide_env = [] {
-        const char *e = std::getenv("AA_W1024_WIDE");
-        return !(e && e[0] == '0');
-    }();
-    const bool wide = wide_env && out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    // aligned nontemporal row stores need a 16-byte-aligned output buffer
+    const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave1024_kind<kComplex>(packed, wide, x, out, table, frame_begin, n_frames, hop,
-                                              frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kMag:
-        return launch_wave1024_kind<kMag>(packed, wide, x, out, table, frame_begin, n_frames, hop,
-                                          frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kPower:
-        return launch_wave1024_kind<kPower>(packed, wide, x, out, table, frame_begin, n_frames, hop,
-                                            frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kLogPower:
-        return launch_wave1024_kind<kLogPower>(packed, wide, x, out, table, frame_begin, n_frames, hop,
-                                               frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     default:
         return hipErrorInvalidValue;
     }
@@ -1691,6 +1345,6 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
     return hipGetLastError();
 }
 
-#endif  // !AA_STAMPS && !AA_ABLATE
+#endif  // AA_ABLATE
 
 }  // namespace aa

@@ -1,6 +1,6 @@
 // Diagnostic (never shipped): times the v3 kernel with parts removed (outputs are wrong by
 // construction; only the time matters) to find what the real pipeline is bound by.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DAA_ABLATE -I audio_analyzer_rs_amd/csrc -o tools/bin/ablate_w1024 tools/ablate_w1024.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-strict-aliasing -DAA_ABLATE -I audio_analyzer_rs_amd/csrc -o tools/bin/ablate_w1024 tools/ablate_w1024.hip
 #include "aa_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -18,7 +18,7 @@ double run(int fpw, const char *name, int force_per_cu = 0)
     const int64_t chunks = (n_frames + fpw - 1) / fpw;
     const size_t lds = aa::wave1024_lds_bytes(fpw, hop);
     int per_cu = 1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_v5_kernel<aa::kMag, ABL, true>, 256, lds);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_kernel<aa::kMag, ABL, true>, 256, lds);
     if (force_per_cu) per_cu = force_per_cu;
     int grid = 256 * per_cu;
     hipEvent_t e0, e1;
@@ -27,7 +27,7 @@ double run(int fpw, const char *name, int force_per_cu = 0)
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL((aa::stft_wave1024_v5_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+            hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
                                (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
@@ -75,11 +75,17 @@ int main(int argc, char **argv)
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < 8; ++i) run<0>(fpw, "warm-up (ignore)");
-    run<0>(fpw, "full kernel, E2 in registers");
-    run<128>(fpw, "full kernel, E2 through LDS");
-    run<0>(fpw, "full kernel, E2 in registers");
-    run<128>(fpw, "full kernel, E2 through LDS");
-    run<1|8|32>(fpw, "compute only, E2 regs");
-    run<1|8|32|128>(fpw, "compute only, E2 LDS");
+    for (int pc : {2, 3, 4, 5}) run<0>(fpw, "full kernel", pc);
+    run<1>(fpw, "no global stores");
+    run<256>(fpw, "stores hit 32 L2-resident rows");
+    run<2>(fpw, "no E2 (register exchange)");
+    run<4>(fpw, "no E1 (LDS exchange)");
+    run<8>(fpw, "no DMA after first chunk");
+    run<16>(fpw, "no split strip");
+    run<32>(fpw, "no per-chunk wait+barrier (+races)");
+    run<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier");
+    run<2 | 4 | 16>(fpw, "no exchanges at all");
+    run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)");
+    run<0>(fpw, "full kernel (again)");
     return 0;
 }
