@@ -97,6 +97,8 @@ SIGNATURES = {
     "aa_host_unregister": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_downmix_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                          ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_onset_flux_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "aa_shard_frames": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]),
     "aa_shard_samples": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.c_int32, _i64p, _i64p]),

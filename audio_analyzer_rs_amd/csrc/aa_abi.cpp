@@ -817,6 +817,17 @@ int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t ch
     return AA_OK;
 }
 
+// ------------------------------------------------------------------- onset front --
+int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
+                         const float *prev_row_dev, float *flux_dev, float *energy_dev, void *stream)
+{
+    if (!mags_dev || !flux_dev || !energy_dev || n_frames < 0 || n_bins < 2)
+        return fail(AA_ERR_ARG, "aa_onset_flux_device: bad argument");
+    AA_HIP(aa::launch_onset_flux(mags_dev, prev_row_dev, flux_dev, energy_dev, n_frames, n_bins,
+                                 (hipStream_t)stream));
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------------- sharding --
 int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *f0, int64_t *f1)
 {

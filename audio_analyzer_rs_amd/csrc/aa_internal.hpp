@@ -83,6 +83,8 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
 hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
                             float *C, int64_t n_rows, int K, int n_cols, int n_pad, float log_floor,
                             hipStream_t stream);
+hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
+                             int64_t n_frames, int n_bins, hipStream_t stream);
 hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int channels,
                           hipStream_t stream);
 

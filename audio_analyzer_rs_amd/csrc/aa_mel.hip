@@ -121,6 +121,45 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float *__rest
     }
 }
 
+// Onset front end (src/analysis/onset.rs:261-291), first of the "next" rows after the STFT:
+// per frame the 3-bin-smoothed, frequency-weighted positive spectral flux against the previous
+// frame's magnitudes and the frame energy.  One wave per frame; the reference's running f32
+// sums become wave reductions (different summation order: tolerance, not bit-exact).
+__global__ __launch_bounds__(256) void onset_flux_kernel(const float *__restrict__ mags,
+                                                         const float *__restrict__ prev0,
+                                                         float *__restrict__ flux,
+                                                         float *__restrict__ energy, int64_t n_frames,
+                                                         int n_bins)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t t = wave0; t < n_frames; t += nwaves) {
+        const float *m = mags + t * n_bins;
+        const float *pv = t == 0 ? prev0 : m - n_bins;
+        float fl = 0.0f, en = 0.0f;
+        for (int i = lane; i < n_bins; i += 64) {
+            const float mag = m[i];
+            en += mag;
+            const float sm = (i == 0 || i >= n_bins - 1) ? mag : (m[i - 1] + mag + m[i + 1]) / 3.0f;
+            // the reference forms weight = 1.0 - (i as f32 / half_size as f32): same expression
+            const float weight = 1.0f - (float)i / (float)n_bins;
+            const float diff = sm - (pv ? pv[i] : 0.0f);
+            if (diff > 0.0f)
+                fl += diff * weight;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            fl += __shfl_xor(fl, off);
+            en += __shfl_xor(en, off);
+        }
+        if (lane == 0) {
+            flux[t] = fl;
+            energy[t] = en;
+        }
+    }
+}
+
 // mixed = (sum of the first min(channels, 2) channels) / that count — mod.rs:784-794
 __global__ void downmix_kernel(const float *__restrict__ in, float *__restrict__ out,
                                int64_t n_frames, int channels)
@@ -153,6 +192,19 @@ hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float 
     else
         hipLaunchKernelGGL(rows_gemm_mfma_kernel<false>, grid, dim3(256), 0, stream, A, lda, B, tk, C, n_rows,
                            K, n_cols, n_pad, log_floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
+                             int64_t n_frames, int n_bins, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    int64_t blocks = (n_frames + 3) / 4;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(onset_flux_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mags, prev0, flux,
+                       energy, n_frames, n_bins);
     return hipGetLastError();
 }
 

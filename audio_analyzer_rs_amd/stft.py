@@ -133,6 +133,26 @@ def downmix(interleaved, channels, stream=None):
     return out
 
 
+def onset_flux(mags, prev_row=None, stream=None):
+    """Spectral flux and frame energy of the onset detector's front end
+    (src/analysis/onset.rs:261-291) for a CUDA float32 magnitude spectrogram [frames, bins].
+    Returns (flux, energy), two CUDA float32 vectors of length frames."""
+    import torch
+
+    lib = _lib.load()
+    if not (mags.is_cuda and mags.dtype == torch.float32 and mags.dim() == 2 and mags.is_contiguous()):
+        raise _lib.AaError(_lib.AA_ERR_ARG, "mags must be a contiguous 2-D CUDA float32 tensor")
+    nf, nb = mags.shape
+    flux = torch.empty(nf, dtype=torch.float32, device=mags.device)
+    energy = torch.empty(nf, dtype=torch.float32, device=mags.device)
+    st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
+    if nf:
+        _lib.check(lib.aa_onset_flux_device(mags.data_ptr(), nf, nb,
+                                            prev_row.data_ptr() if prev_row is not None else None,
+                                            flux.data_ptr(), energy.data_ptr(), st))
+    return flux, energy
+
+
 class StftStream:
     """Streaming front end: the ring-buffer ingest of stft.rs:198-201, 240-266 feeding the
     GPU frame loop.  `push(slot)` appends one slot (the reference's are 1024 samples,

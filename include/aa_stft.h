@@ -166,6 +166,20 @@ int aa_host_unregister(void *ptr);
 int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t channels,
                       float *mono_dev, void *stream);
 
+/* ---- onset front end: spectral flux + frame energy (src/analysis/onset.rs:261-291) ---- */
+/* First stage after the onset STFT: for every frame t of a magnitude
+ * spectrogram mags_dev[n_frames][n_bins] (AA_OUT_MAG rows; the reference geometry is 256/64,
+ * n_bins = 129)
+ *   energy[t] = sum_i mag[t][i]
+ *   flux[t]   = sum_i max(0, smooth3(mag[t])[i] - mag[t-1][i]) * (1 - i/n_bins)
+ * with smooth3 the 3-bin mean (ends unsmoothed) and mag[-1] = prev_row_dev (NULL = zeros, the
+ * detector's initial state, onset.rs:146; a shard passes its predecessor's last row).  The
+ * reference accumulates in bin order in f32; here each frame is a wave reduction, so parity is
+ * to 1e-5 relative, not bit-exact.  The detector logic after it (burst floors, FluxTracker,
+ * gates: onset.rs:293-546) is sequential per stream and stays on the host. */
+int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
+                         const float *prev_row_dev, float *flux_dev, float *energy_dev, void *stream);
+
 /* ---- frame-range sharding (one rank per GPU) --------------- */
 /* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs
  * samples [f0*hop, (f1-1)*hop + n_fft) — a halo of n_fft-hop samples shared with

@@ -14,6 +14,7 @@ from .capi import (  # noqa: F401
     build_oracle,
     hann_window,
     num_frames,
+    onset_flux,
     rfft_forward,
     rfft_inverse,
     stft,

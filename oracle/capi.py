@@ -58,6 +58,8 @@ class Oracle:
         lib.aao_stream_push.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int, _i64p, _f32p,
                                         ctypes.c_int64]
         lib.aao_stream_push.restype = ctypes.c_int64
+        lib.aao_onset_flux.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p]
+        lib.aao_onset_flux.restype = None
         lib.aao_lcg_next.argtypes = [ctypes.c_uint32]
         lib.aao_lcg_next.restype = ctypes.c_uint32
         self.lib = lib
@@ -174,3 +176,15 @@ def stream_frame_starts(slot_lens, n_fft, hop, ring_len, slot_data=None, return_
         return np.array(starts, dtype=np.int64), (np.concatenate(frames) if frames else
                                                   np.empty((0, n_fft), np.float32))
     return np.array(starts, dtype=np.int64)
+
+
+def onset_flux(mags, prev0=None):
+    """Spectral flux and frame energy (src/analysis/onset.rs:261-291), sequential f32."""
+    mags = np.ascontiguousarray(mags, dtype=np.float32)
+    nf, nb = mags.shape
+    flux = np.empty(nf, dtype=np.float32)
+    energy = np.empty(nf, dtype=np.float32)
+    p0 = None if prev0 is None else np.ascontiguousarray(prev0, dtype=np.float32)
+    Oracle.get().lib.aao_onset_flux(_ptr(mags), nf, nb, _ptr(p0) if p0 is not None else None,
+                                    _ptr(flux), _ptr(energy))
+    return flux, energy

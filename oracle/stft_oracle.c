@@ -405,6 +405,38 @@ int64_t aao_stream_push(aao_stream *s, const float *slot, int slot_len,
     return emitted;
 }
 
+/* ------------------------------------------- onset front: flux and energy -- */
+
+/* Spectral flux and frame energy of OnsetDetector::detect_onsets
+ * (src/analysis/onset.rs:261-291), sequential f32 sums in bin order:
+ *   energy   += mag[i]
+ *   smoothed  = i == 0 || i >= n-1 ? mag[i] : (mag[i-1] + mag[i] + mag[i+1]) / 3
+ *   weight    = 1 - i / n
+ *   diff      = smoothed - prev[i];  if diff > 0: flux += diff * weight
+ *   prev[i]   = mag[i]                     (prev starts at zero, onset.rs:146)
+ * mags: [n_frames x n_bins]; prev0: n_bins values carried in from the frame
+ * before the first one (NULL = zeros).                                          */
+void aao_onset_flux(const float *mags, int64_t n_frames, int n_bins, const float *prev0,
+                    float *flux, float *energy)
+{
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const float *m = mags + t * (int64_t)n_bins;
+        const float *pv = t == 0 ? prev0 : m - n_bins;
+        float fl = 0.0f, en = 0.0f;
+        for (int i = 0; i < n_bins; ++i) {
+            float mag = m[i];
+            en += mag;
+            float sm = (i == 0 || i >= n_bins - 1) ? mag : (m[i - 1] + m[i] + m[i + 1]) / 3.0f;
+            float weight = 1.0f - ((float)i / (float)n_bins);
+            float diff = sm - (pv ? pv[i] : 0.0f);
+            if (diff > 0.0f)
+                fl += diff * weight;
+        }
+        flux[t] = fl;
+        energy[t] = en;
+    }
+}
+
 /* ------------------------------------------------------ synthetic signals -- */
 
 /* LCG of the reference's metronome noise tick (src/generators/metronome.rs:56-57):

@@ -316,6 +316,23 @@ def test_downmix_matches_capture_rule(aa, torch_mod):
         assert torch_mod.allclose(got, ref, rtol=0, atol=1e-7)
 
 
+def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
+    """First "next" row: spectral flux + frame energy of the onset detector
+    (onset.rs:261-291) on the onset geometry, against the sequential f32 restatement."""
+    n, hop = 256, 64
+    x = aa.signals.synth_corpus(31337, n + 4999 * hop)
+    x[20_000:20_400] += 0.5 * aa.signals.lcg_noise(7, 0, 400).astype(np.float32)     # a burst
+    mags = aa.Stft(n, hop, output="mag")(torch_mod.from_numpy(x).cuda())
+    flux, energy = aa.onset_flux(mags)
+    rf, re = oracle_mod.onset_flux(mags.cpu().numpy())
+    assert flux.shape == (5000,)
+    assert np.max(np.abs(flux.cpu().numpy() - rf) / np.maximum(np.abs(rf), 1e-3)) < 1e-5
+    assert np.max(np.abs(energy.cpu().numpy() - re) / np.abs(re)) < 1e-5
+    # shards: second half with the last row of the first half carried in == whole
+    f2, e2 = aa.onset_flux(mags[2500:].contiguous(), prev_row=mags[2499].contiguous())
+    assert torch_mod.equal(f2, flux[2500:]) and torch_mod.equal(e2, energy[2500:])
+
+
 # --------------------------------------------------------- FftProcessor (fft.rs:6-42) --
 @pytest.mark.parametrize("n", [4, 16, 256, 1024, 2048, 8192, 6, 100])
 def test_fft_processor_forward_inverse(aa, oracle_mod, n):

@@ -104,6 +104,21 @@ def test_stream_overflow_drops_oldest(oracle_mod):
     assert np.all(np.diff(starts[13:]) == 64)
 
 
+def test_onset_flux_restatement(oracle_mod):
+    # onset.rs:261-291 on a hand-checkable case: 2 frames x 5 bins, prev = 0
+    m = np.array([[1, 2, 3, 4, 5], [5, 4, 3, 2, 1]], dtype=np.float32)
+    flux, energy = oracle_mod.onset_flux(m)
+    assert np.allclose(energy, [15, 15])
+    w = 1 - np.arange(5) / 5
+    sm0 = np.array([1, 2, 3, 4, 5.0])          # smoothing of a linear ramp is the ramp
+    assert np.isclose(flux[0], np.sum(sm0 * w))
+    d1 = np.array([5, 4, 3, 2, 1.0]) - m[0]
+    assert np.isclose(flux[1], np.sum(np.maximum(d1, 0) * w))
+    # carrying the previous row in == computing the two shards as one
+    f2, e2 = oracle_mod.onset_flux(m[1:], prev0=m[0])
+    assert f2[0] == flux[1] and e2[0] == energy[1]
+
+
 def test_oracle_header_says_parity_unpinned():
     import os
 
