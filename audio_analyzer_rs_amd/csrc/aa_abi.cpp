@@ -828,6 +828,18 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
     return AA_OK;
 }
 
+// ------------------------------------------------------------------- tuner front --
+int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
+                          const float *global_floor_dev, float *state_dev, int32_t initialized,
+                          float *eff_floor_dev, void *stream)
+{
+    if (!mags_dev || !global_floor_dev || !state_dev || !eff_floor_dev || n_frames < 0 || n_bins < 1)
+        return fail(AA_ERR_ARG, "aa_tuner_floor_device: bad argument");
+    AA_HIP(aa::launch_tuner_floor(mags_dev, global_floor_dev, state_dev, initialized, eff_floor_dev,
+                                  n_frames, n_bins, (hipStream_t)stream));
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------------- sharding --
 int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *f0, int64_t *f1)
 {

@@ -85,6 +85,9 @@ hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float 
                             hipStream_t stream);
 hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
                              int64_t n_frames, int n_bins, hipStream_t stream);
+hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
+                              int initialized, float *eff, int64_t n_frames, int n_bins,
+                              hipStream_t stream);
 hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int channels,
                           hipStream_t stream);
 

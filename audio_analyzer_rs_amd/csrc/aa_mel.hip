@@ -160,6 +160,53 @@ __global__ __launch_bounds__(256) void onset_flux_kernel(const float *__restrict
     }
 }
 
+// Tuner front end (src/audio_io/stft.rs:326-367), first stage of "next" row f-1: the variance-
+// aware per-bin noise floor.  It is a recurrence over frames, independent per bin: one lane per
+// bin walks the frames in order with exactly the reference's operation order (contraction off,
+// IEEE division), so the result is bit-identical to the CPU restatement.  Parallelism is only
+// n_bins lanes per stream; rows are read and written coalesced across bins.
+__global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict__ mags,
+                                                         const float *__restrict__ global_floor,
+                                                         float *__restrict__ state, int initialized,
+                                                         float *__restrict__ eff, int64_t n_frames,
+                                                         int n_bins)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_bins)
+        return;
+    const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
+    const float VOL_MEMORY = 0.75f, NOTE_RATIO = 1.5f, NOTE_VOL_MAX = 0.15f;
+    float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
+    bool init = initialized != 0;
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const float mag = mags[t * n_bins + k];
+        const float gf = global_floor[t];
+        if (!init) {
+            fl = fmaxf(mag, gf * 5.0f);
+            prev = mag;
+            init = true;
+        } else {
+            const float delta = fabsf(mag - prev);
+            vol = vol * VOL_MEMORY + delta * (1.0f - VOL_MEMORY);
+            prev = mag;
+            const float above_ratio = mag / fmaxf(fl, 0.01f);
+            float vn = vol / fmaxf(mag, 0.05f);
+            vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
+            const bool sustained = above_ratio > NOTE_RATIO && vn < NOTE_VOL_MAX;
+            if (!sustained) {
+                const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn
+                                             : FLOOR_RELEASE;
+                fl = fl + alpha * (mag - fl);
+            }
+        }
+        eff[t * n_bins + k] = fminf(fl, gf * 2.5f);
+    }
+    state[k] = fl;
+    state[n_bins + k] = prev;
+    state[2 * n_bins + k] = vol;
+}
+
 // mixed = (sum of the first min(channels, 2) channels) / that count — mod.rs:784-794
 __global__ void downmix_kernel(const float *__restrict__ in, float *__restrict__ out,
                                int64_t n_frames, int channels)
@@ -205,6 +252,17 @@ hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux,
         blocks = 8192;
     hipLaunchKernelGGL(onset_flux_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mags, prev0, flux,
                        energy, n_frames, n_bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
+                              int initialized, float *eff, int64_t n_frames, int n_bins,
+                              hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(tuner_floor_kernel, dim3((unsigned)((n_bins + 63) / 64)), dim3(64), 0, stream, mags,
+                       global_floor, state, initialized, eff, n_frames, n_bins);
     return hipGetLastError();
 }
 

@@ -153,6 +153,26 @@ def onset_flux(mags, prev_row=None, stream=None):
     return flux, energy
 
 
+def tuner_floor(mags, global_floor, state=None, stream=None):
+    """Per-bin adaptive noise floor of the tuner (src/audio_io/stft.rs:326-367) for a CUDA float32
+    magnitude spectrogram [frames, bins].  global_floor: CUDA float32 [frames]
+    (= 10^(noise_floor_db/20) * bins / 2 per frame).  state: None for a fresh stream, or the
+    [3, bins] tensor returned by a previous call.  Returns (effective_floor, state)."""
+    import torch
+
+    lib = _lib.load()
+    nf, nb = mags.shape
+    initialized = state is not None
+    if state is None:
+        state = torch.zeros((3, nb), dtype=torch.float32, device=mags.device)
+    eff = torch.empty_like(mags)
+    st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
+    if nf:
+        _lib.check(lib.aa_tuner_floor_device(mags.data_ptr(), nf, nb, global_floor.data_ptr(),
+                                             state.data_ptr(), 1 if initialized else 0, eff.data_ptr(), st))
+    return eff, state
+
+
 class StftStream:
     """Streaming front end: the ring-buffer ingest of stft.rs:198-201, 240-266 feeding the
     GPU frame loop.  `push(slot)` appends one slot (the reference's are 1024 samples,

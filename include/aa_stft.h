@@ -180,6 +180,24 @@ int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t ch
 int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
                          const float *prev_row_dev, float *flux_dev, float *energy_dev, void *stream);
 
+/* ---- tuner front end: per-bin adaptive noise floor (src/audio_io/stft.rs:326-367) ---- */
+/* First stage after the tuner STFT.  For every bin a first-order
+ * recurrence over frames with the reference's constants (stft.rs:219-224):
+ *   first frame:  floor = max(mag, 5*global_floor); prev = mag
+ *   later:        vol = 0.75*vol + 0.25*|mag - prev|; prev = mag;
+ *                 sustained = mag/max(floor,0.01) > 1.5 && clamp(vol/max(mag,0.05),0,1) < 0.15;
+ *                 if !sustained: floor += (mag > floor ? 0.04 + 0.31*vol_norm : 0.02)*(mag - floor)
+ *   eff_floor[t][k] = min(floor[k], 2.5*global_floor[t])
+ * global_floor_dev[t] = 10^(noise_floor_db/20) * n_bins / 2 (stft.rs:322-324) comes from the
+ * caller.  state_dev holds 3*n_bins floats {floor, prev_mag, volatility} and is updated in
+ * place, `initialized` says whether it carries a previous call's state — so a stream can be fed
+ * in pieces.  One lane per bin walks the frames in order with the reference's operation order:
+ * results are bit-identical to the sequential f32 evaluation.  The pitch extraction and
+ * PitchTracker that consume eff_floor (stft.rs:443-620, 28-117) stay on the host. */
+int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
+                          const float *global_floor_dev, float *state_dev, int32_t initialized,
+                          float *eff_floor_dev, void *stream);
+
 /* ---- frame-range sharding (one rank per GPU) --------------- */
 /* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs
  * samples [f0*hop, (f1-1)*hop + n_fft) — a halo of n_fft-hop samples shared with

@@ -19,5 +19,6 @@ from .capi import (  # noqa: F401
     rfft_inverse,
     stft,
     stream_frame_starts,
+    tuner_floor,
 )
 from . import truth  # noqa: F401

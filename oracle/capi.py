@@ -60,6 +60,9 @@ class Oracle:
         lib.aao_stream_push.restype = ctypes.c_int64
         lib.aao_onset_flux.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p]
         lib.aao_onset_flux.restype = None
+        lib.aao_tuner_floor.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p,
+                                        ctypes.POINTER(ctypes.c_int), _f32p]
+        lib.aao_tuner_floor.restype = None
         lib.aao_lcg_next.argtypes = [ctypes.c_uint32]
         lib.aao_lcg_next.restype = ctypes.c_uint32
         self.lib = lib
@@ -188,3 +191,16 @@ def onset_flux(mags, prev0=None):
     Oracle.get().lib.aao_onset_flux(_ptr(mags), nf, nb, _ptr(p0) if p0 is not None else None,
                                     _ptr(flux), _ptr(energy))
     return flux, energy
+
+
+def tuner_floor(mags, global_floor, state=None, initialized=False):
+    """Per-bin adaptive noise floor of the tuner (src/audio_io/stft.rs:326-367).
+    Returns (effective_floor [frames, bins], state [3, bins], initialized)."""
+    mags = np.ascontiguousarray(mags, dtype=np.float32)
+    nf, nb = mags.shape
+    gf = np.ascontiguousarray(np.broadcast_to(np.asarray(global_floor, dtype=np.float32), (nf,)))
+    st = np.zeros((3, nb), dtype=np.float32) if state is None else np.array(state, dtype=np.float32)
+    init = ctypes.c_int(1 if initialized else 0)
+    eff = np.empty((nf, nb), dtype=np.float32)
+    Oracle.get().lib.aao_tuner_floor(_ptr(mags), nf, nb, _ptr(gf), _ptr(st), ctypes.byref(init), _ptr(eff))
+    return eff, st, bool(init.value)

@@ -437,6 +437,52 @@ void aao_onset_flux(const float *mags, int64_t n_frames, int n_bins, const float
     }
 }
 
+/* -------------------------------------- tuner front: per-bin noise floor -- */
+
+/* Variance-aware per-bin noise floor of STFT::detect_pitches
+ * (src/audio_io/stft.rs:206-224 constants, :326-367 update): a first-order recurrence over
+ * frames for every bin.  state = {floor[n], prev_mag[n], volatility[n]} (3*n floats) plus the
+ * `initialized` flag; global_floor = 10^(noise_floor_db/20) * half_size / 2 is supplied by the
+ * caller (one value per frame, stft.rs:322-324).  eff[t][k] = min(floor[k], 2.5*global_floor).
+ * Plain f32, one rounding per operation as Rust evaluates it (build with -ffp-contract=off). */
+void aao_tuner_floor(const float *mags, int64_t n_frames, int n_bins, const float *global_floor,
+                     float *state, int *initialized, float *eff)
+{
+    const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
+    const float VOL_MEMORY = 0.75f, NOTE_RATIO = 1.5f, NOTE_VOL_MAX = 0.15f;
+    float *floor_ = state, *prev = state + n_bins, *vol = state + 2 * n_bins;
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const float *m = mags + t * (int64_t)n_bins;
+        const float gf = global_floor[t];
+        if (!*initialized) {
+            for (int k = 0; k < n_bins; ++k) {
+                floor_[k] = fmaxf(m[k], gf * 5.0f);
+                prev[k] = m[k];
+            }
+            *initialized = 1;
+        } else {
+            for (int k = 0; k < n_bins; ++k) {
+                float mag = m[k], fl = floor_[k];
+                float delta = fabsf(mag - prev[k]);
+                vol[k] = vol[k] * VOL_MEMORY + delta * (1.0f - VOL_MEMORY);
+                prev[k] = mag;
+                float above_ratio = mag / fmaxf(fl, 0.01f);
+                float vn = vol[k] / fmaxf(mag, 0.05f);
+                vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
+                int sustained = above_ratio > NOTE_RATIO && vn < NOTE_VOL_MAX;
+                if (!sustained) {
+                    float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn
+                                           : FLOOR_RELEASE;
+                    floor_[k] = fl + alpha * (mag - fl);
+                }
+            }
+        }
+        float *e = eff + t * (int64_t)n_bins;
+        for (int k = 0; k < n_bins; ++k)
+            e[k] = fminf(floor_[k], gf * 2.5f);
+    }
+}
+
 /* ------------------------------------------------------ synthetic signals -- */
 
 /* LCG of the reference's metronome noise tick (src/generators/metronome.rs:56-57):

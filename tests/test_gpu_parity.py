@@ -333,6 +333,27 @@ def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
     assert torch_mod.equal(f2, flux[2500:]) and torch_mod.equal(e2, energy[2500:])
 
 
+def test_tuner_noise_floor_bit_exact(aa, oracle_mod, torch_mod):
+    """First stage of "next" row f-1: the tuner's per-bin adaptive noise floor
+    (stft.rs:326-367) on the tuner geometry — a recurrence, evaluated in the reference's
+    operation order: bit-identical to the sequential f32 restatement, also when fed in pieces."""
+    n, hop = 2048, 512
+    x = aa.signals.synth_corpus(777, n + 2999 * hop)
+    x[400_000:420_000] *= 0.05                               # a quiet passage
+    mags = aa.Stft(n, hop, output="mag")(torch_mod.from_numpy(x).cuda())
+    nb = mags.shape[1]
+    gf_db = -60.0 + 10.0 * np.sin(np.arange(3000) / 200.0)   # a slowly moving noise_floor_db
+    gf = (10.0 ** (gf_db / 20.0) * nb / 2.0).astype(np.float32)
+    gfd = torch_mod.from_numpy(gf).cuda()
+    eff, state = aa.tuner_floor(mags, gfd)
+    ref_eff, ref_state, _ = oracle_mod.tuner_floor(mags.cpu().numpy(), gf)
+    assert np.array_equal(eff.cpu().numpy(), ref_eff)
+    assert np.array_equal(state.cpu().numpy(), ref_state)
+    e1, s1 = aa.tuner_floor(mags[:1234].contiguous(), gfd[:1234].contiguous())
+    e2, s2 = aa.tuner_floor(mags[1234:].contiguous(), gfd[1234:].contiguous(), state=s1)
+    assert torch_mod.equal(torch_mod.cat([e1, e2]), eff) and torch_mod.equal(s2, state)
+
+
 # --------------------------------------------------------- FftProcessor (fft.rs:6-42) --
 @pytest.mark.parametrize("n", [4, 16, 256, 1024, 2048, 8192, 6, 100])
 def test_fft_processor_forward_inverse(aa, oracle_mod, n):

@@ -119,6 +119,27 @@ def test_onset_flux_restatement(oracle_mod):
     assert f2[0] == flux[1] and e2[0] == energy[1]
 
 
+def test_tuner_floor_restatement(oracle_mod):
+    # stft.rs:326-367 — first frame initialises, a steady loud bin freezes, quiet bins release
+    nb = 4
+    mags = np.tile(np.array([[10.0, 0.5, 0.02, 1.0]], np.float32), (50, 1))
+    gf = 0.1
+    eff, st, init = oracle_mod.tuner_floor(mags, gf)
+    assert init and eff.shape == (50, nb)
+    # frame 0: floor = max(mag, 5*gf) ; eff = min(floor, 2.5*gf)
+    assert np.allclose(eff[0], np.minimum(np.maximum(mags[0], 0.5), 0.25))
+    # constant input -> zero volatility; bin 0 is 20x above its floor of 10? no: floor starts AT mag
+    assert np.allclose(st[1], mags[0])                      # prev_mag
+    assert np.all(st[2] == 0.0)                             # volatility
+    # feeding in two pieces with the carried state == one piece
+    e1, s1, i1 = oracle_mod.tuner_floor(mags[:20] * np.linspace(1, 2, 20, dtype=np.float32)[:, None], gf)
+    x = mags * 1.0
+    x[:20] *= np.linspace(1, 2, 20, dtype=np.float32)[:, None]
+    ea, sa, _ = oracle_mod.tuner_floor(x, gf)
+    eb, sb, _ = oracle_mod.tuner_floor(x[20:], gf, state=s1, initialized=i1)
+    assert np.array_equal(ea[20:], eb) and np.array_equal(sa, sb)
+
+
 def test_oracle_header_says_parity_unpinned():
     import os
 
