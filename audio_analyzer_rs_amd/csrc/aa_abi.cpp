@@ -144,6 +144,7 @@ void build_wave1024_table(const float *window, std::vector<float> *tab)
     }
 }
 
+constexpr int64_t kMfccSlab = 262144; // frames per log-mel slab of the fused MFCC path
 constexpr int64_t kMelSlab = 32768;  // frames per power-spectrogram slab (<= 134 MB: Infinity-Cache resident; 256 GEMM workgroups)
 
 // Slaney mel scale (linear below 1 kHz, log above) — the build's definition of AA_OUT_LOGMEL
@@ -179,6 +180,86 @@ void mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax, std
             (*w)[(size_t)i * nb + k] = v > 0.0 ? v * enorm : 0.0;
         }
     }
+}
+
+// Parameters and schedule of the fused mel reduction (aa_internal.hpp: MelSched): the same Slaney
+// triangles as mel_filterbank, as two lines per filter in bin units.  `lanes` lanes reduce one
+// frame (64 at n_fft 2048, 32 at 1024).  The mels are cut into <= kMelMaxGroups groups of
+// lanes >> pl consecutive mels (pl = 0, 1, 2: 1, 2 or 4 K-slices per filter); a small dynamic
+// programme picks the cut that minimises sum(trips + per-group overhead).  k_start is pulled
+// down so that every slice stays inside the row (weights below the filter's first bin evaluate
+// to 0 through med3).
+bool build_mel_sched(int sr, int n_fft, int n_mels, double fmin, double fmax, int lanes,
+                     std::vector<float> *par, aa::MelSched *sch)
+{
+    const int nb = n_fft / 2 + 1;
+    if (n_mels < 1 || n_mels > aa::kMelMaxMels)
+        return false;
+    std::vector<double> c(n_mels + 2), hz(n_mels + 2);
+    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) {
+        hz[i] = mel_to_hz(m0 + (m1 - m0) * (double)i / (double)(n_mels + 1));
+        c[i] = hz[i] * n_fft / sr;
+    }
+    std::vector<int> k_lo(n_mels), len(n_mels);
+    for (int m = 0; m < n_mels; ++m) {
+        k_lo[m] = std::max(0, (int)std::floor(c[m]) + 1);                     // first k > c[m]
+        const int k_hi = std::min(nb - 1, (int)std::ceil(c[m + 2]) - 1);      // last  k < c[m+2]
+        len[m] = std::max(0, k_hi - k_lo[m] + 1);
+    }
+    auto trips_of = [&](int first, int pl) {
+        int widest = 0;
+        for (int m = first; m < std::min(n_mels, first + (lanes >> pl)); ++m)
+            widest = std::max(widest, len[m]);
+        return ((widest + (1 << pl) - 1) / (1 << pl) + 3) / 4 * 4;   // the kernel steps 4 bins at a time
+    };
+    // best[j][m]: cheapest way to cover mels [m, n_mels) with exactly j more groups
+    const int G = aa::kMelMaxGroups, kOverhead = 8, kInf = 1 << 28;
+    std::vector<std::vector<int>> best(G + 1, std::vector<int>(n_mels + 1, kInf)), pick = best;
+    best[0][n_mels] = 0;
+    for (int j = 1; j <= G; ++j)
+        for (int m = n_mels - 1; m >= 0; --m)
+            for (int pl = 0; pl <= 2; ++pl) {
+                const int next = std::min(n_mels, m + (lanes >> pl));
+                const int t = trips_of(m, pl);
+                if ((t << pl) > nb || best[j - 1][next] >= kInf)
+                    continue;
+                const int cost = best[j - 1][next] + t + kOverhead;
+                if (cost < best[j][m]) {
+                    best[j][m] = cost;
+                    pick[j][m] = pl;
+                }
+            }
+    int jbest = 0;
+    for (int j = 1; j <= G; ++j)
+        if (best[j][0] < (jbest ? best[jbest][0] : kInf))
+            jbest = j;
+    if (!jbest)
+        return false;
+    par->assign(aa::kMelParTableDwords, 0.0f);
+    *sch = aa::MelSched();
+    sch->n_mels = n_mels;
+    sch->n_groups = jbest;
+    for (int g = 0, m = 0, j = jbest; j > 0; ++g, --j) {
+        const int pl = pick[j][m], parts = 1 << pl, trips = trips_of(m, pl);
+        const int next = std::min(n_mels, m + (lanes >> pl));
+        sch->trips[g] = trips;
+        sch->mel_base[g] = m;
+        sch->part_log2[g] = pl;
+        for (int i = m; i < next; ++i) {
+            const int ks = std::max(0, std::min(k_lo[i], nb - parts * trips));
+            const double e = 2.0 / (hz[i + 2] - hz[i]);
+            const double iu = 1.0 / (c[i + 1] - c[i]), id = 1.0 / (c[i + 2] - c[i + 1]);
+            float *q = par->data() + (size_t)aa::kMelParDwords * i;
+            std::memcpy(&q[0], &ks, sizeof(int));
+            q[1] = (float)(e * ((double)ks - c[i]) * iu);
+            q[2] = (float)(e * iu);
+            q[3] = (float)(e * (c[i + 2] - (double)ks) * id);
+            q[4] = (float)(e * id);
+        }
+        m = next;
+    }
+    return true;
 }
 
 // Per-lane constants of the wave-per-frame 2048 kernel, [kWave2048Rows][64] (row meaning in
@@ -280,8 +361,13 @@ struct aa_stft_plan {
     float *d_dct = nullptr;        // DCT-II matrix transposed, [n_mels_pad32 x n_mfcc_pad]
     int *d_dct_tile_k = nullptr;   // full K range per 32-coefficient tile
     int n_mfcc_pad = 0;
-    float *d_ws_power = nullptr;   // [kMelSlab x n_bins]
-    float *d_ws_logmel = nullptr;  // [kMelSlab x n_mels]
+    float *d_ws_power = nullptr;   // [kMelSlab x n_bins], GEMM path only (allocated on first use)
+    float *d_ws_logmel = nullptr;  // [ws_logmel_rows x n_mels]
+    int64_t ws_logmel_rows = 0;
+    // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
+    bool fused_mel = false;
+    float *d_mel_par = nullptr;    // [kMelParTableDwords]
+    aa::MelSched mel_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
     hipStream_t pipe_stream[2] = {nullptr, nullptr};
     hipEvent_t pipe_event = nullptr;
@@ -519,7 +605,6 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             AA_HIP(hipMemcpy(p->d_melT, melT.data(), melT.size() * sizeof(float), hipMemcpyHostToDevice));
             AA_HIP(hipMalloc(&p->d_tile_k, tile_k.size() * sizeof(int)));
             AA_HIP(hipMemcpy(p->d_tile_k, tile_k.data(), tile_k.size() * sizeof(int), hipMemcpyHostToDevice));
-            AA_HIP(hipMalloc(&p->d_ws_power, sizeof(float) * (size_t)kMelSlab * nb));
             if (cfg->output == AA_OUT_MFCC) {
                 // DCT-II, orthonormal: d[c][m] = s_c cos(pi c (2m+1) / (2M)), s_0 = sqrt(1/M), else
                 // sqrt(2/M); stored transposed [m][c] (B operand of the GEMM), zero padded
@@ -543,6 +628,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 AA_HIP(hipMalloc(&p->d_dct_tile_k, dtk.size() * sizeof(int)));
                 AA_HIP(hipMemcpy(p->d_dct_tile_k, dtk.data(), dtk.size() * sizeof(int), hipMemcpyHostToDevice));
                 AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)kMelSlab * n_mels));
+                p->ws_logmel_rows = kMelSlab;
             }
         }
         if (cfg->n_fft == 256 && cfg->hop % 4 == 0 && cfg->hop % 2 == 0) {
@@ -591,6 +677,24 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->wave1024 = true;
             }
         }
+        // Fused mel reduction in the wave kernels (the power rows never leave the CU); the slab +
+        // MFMA GEMM path stays for the generic kernels, unaligned input and AA_MEL_GEMM=1.
+        const char *force_gemm = std::getenv("AA_MEL_GEMM");
+        if (mel_out && !(force_gemm && std::atoi(force_gemm) != 0) &&
+            (p->wave2048 || (p->wave1024 && p->frames_per_wg == 8))) {
+            const double fmax = cfg->fmax > 0.0f ? cfg->fmax : cfg->sample_rate / 2.0;
+            std::vector<float> par;
+            const int lanes = p->wave2048 ? 64 : 32;   // one frame per wave pass at 2048, two at 1024
+            const bool mel_lds_ok =
+                (p->wave2048 ? aa::wave2048_lds_dwords(p->frames_per_wg, cfg->hop, true)
+                             : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384;
+            if (mel_lds_ok && build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes,
+                                              &par, &p->mel_sched)) {
+                AA_HIP(hipMalloc(&p->d_mel_par, par.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_mel_par, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
+                p->fused_mel = true;
+            }
+        }
         return AA_OK;
     };
     rc = setup();
@@ -613,7 +717,7 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
             (void)hipStreamDestroy(st);
     if (p->pipe_event)
         (void)hipEventDestroy(p->pipe_event);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct,
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
@@ -688,9 +792,50 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
     };
     if (p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC)
         return fft_stage(p->cfg.output, frame_begin, nf, out_dev);
-    // mel / MFCC: power spectrogram slab -> f32 MFMA filterbank (+log) -> optional DCT.
+    // mel / MFCC, fused: the wave kernel reduces each power row to n_mels log-mel values in LDS
+    // (triangular gather); MFCC adds the dense DCT-II as an f32 MFMA GEMM over log-mel slabs.
+    const float *first_sample = samples_dev + frame_begin * (int64_t)p->cfg.hop;
+    if (p->fused_mel && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
+        auto mel_stage = [&](int64_t fb, int64_t n, float *dst) -> int {
+            if (p->wave2048)
+                AA_HIP(aa::launch_wave2048(aa::kLogMel, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
+            else
+                AA_HIP(aa::launch_wave1024(aa::kLogMel, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
+            return AA_OK;
+        };
+        if (p->cfg.output == AA_OUT_LOGMEL)
+            return mel_stage(frame_begin, nf, out_dev);
+        // log-mel rows are small (n_mels floats): one slab of up to 2^18 frames (<= 134 MB) so the
+        // DCT GEMM runs as one large launch; the buffer grows on first use
+        const int64_t slab = std::min<int64_t>(nf, kMfccSlab);
+        if (slab > p->ws_logmel_rows) {
+            (void)hipFree(p->d_ws_logmel);
+            p->d_ws_logmel = nullptr;
+            p->ws_logmel_rows = 0;
+            AA_HIP(hipMalloc(&p->d_ws_logmel, sizeof(float) * (size_t)slab * p->n_mels));
+            p->ws_logmel_rows = slab;
+        }
+        for (int64_t f = 0; f < nf; f += slab) {
+            const int64_t n = std::min<int64_t>(slab, nf - f);
+            // a slab start must keep the 16-byte input alignment the wave kernels stage with
+            if ((reinterpret_cast<uintptr_t>(samples_dev + (frame_begin + f) * (int64_t)p->cfg.hop) & 15u) != 0)
+                return fail(AA_ERR_ARG, "internal: unaligned MFCC slab");
+            int rc = mel_stage(frame_begin + f, n, p->d_ws_logmel);
+            if (rc != AA_OK)
+                return rc;
+            AA_HIP(aa::launch_rows_gemm(false, p->d_ws_logmel, p->n_mels, p->d_dct, p->d_dct_tile_k,
+                                        out_dev + f * p->n_mfcc, n, p->n_mels, p->n_mfcc, p->n_mfcc_pad,
+                                        0.0f, st));
+        }
+        return AA_OK;
+    }
+    // mel / MFCC, unfused: power spectrogram slab -> f32 MFMA filterbank (+log) -> optional DCT.
     // The slab (<= 34 MB) is re-read by the next kernel out of L2 / Infinity Cache.
     const int nb = p->cfg.n_fft / 2 + 1;
+    if (!p->d_ws_power)
+        AA_HIP(hipMalloc(&p->d_ws_power, sizeof(float) * (size_t)kMelSlab * nb));
     for (int64_t f = 0; f < nf; f += kMelSlab) {
         const int64_t n = std::min<int64_t>(kMelSlab, nf - f);
         int rc = fft_stage(aa::kPower, frame_begin + f, n, p->d_ws_power);

@@ -7,8 +7,34 @@
 
 namespace aa {
 
-// Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER).
-enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3 };
+// Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
+// the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4 };
+
+// ---- fused mel reduction (wave kernels, kLogMel) ------------------------------------
+// The filterbank is triangular: 98 % zeros, every bin feeds at most two filters, so the fused
+// path evaluates it as a gather on the VALU straight from the power row in LDS instead of a
+// dense GEMM.  A wave reduces its F frames (2 at 1024, 1 at 2048) with 64/F lanes per frame; a
+// group g covers (64/F) >> part_log2[g] consecutive mels from mel_base[g], each filter's support
+// cut into 1 << part_log2[g] K-slices of trips[g] bins (narrow low filters: many mels per group,
+// wide high filters: more slices).  The weight of a filter at offset i from its first bin is
+// med3(U0 + i DU, D0 - i DD, 0) (the two edges of the triangle, Slaney norm folded in), so no
+// weight table is needed.
+// Per-mel parameters, kMelParDwords floats each: {k_start (int bits), U0, DU, D0, DD, 0}; entry
+// kMelMaxMels is all zero (lanes past n_mels read it).
+constexpr int kMelMaxMels = 128;
+constexpr int kMelMaxGroups = 8;
+constexpr int kMelParDwords = 6;
+constexpr int kMelParTableDwords = (kMelMaxMels + 1) * kMelParDwords + 2;   // 776, keeps 16-byte size
+constexpr int kMelStageDwords = 256;                // per wave: mel values of up to two frames
+constexpr int kMelLdsDwords = kMelParTableDwords + 4 * kMelStageDwords;
+struct MelSched {
+    int n_mels = 0;
+    int n_groups = 0;
+    int trips[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};       // bins per K-slice (multiples of 4)
+    int mel_base[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int part_log2[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0, 1 or 2
+};
 
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see
@@ -18,34 +44,37 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
 // LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
 // of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
-inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop)
+inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, bool mel = false)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
-    return 2 * span + 4 * kWave1024ScratchDwords;
+    return 2 * span + 4 * kWave1024ScratchDwords + (mel ? kMelLdsDwords : 0);
 }
-inline size_t wave1024_lds_bytes(int frames_per_wg, int hop)
+inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, bool mel = false)
 {
-    return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop);
+    return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop, mel);
 }
 
+// mel_par / sched are used by kLogMel only (null / nullptr otherwise).
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream);
+                           float log_floor, hipStream_t stream, const float *mel_par = nullptr,
+                           const MelSched *sched = nullptr);
 
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;
-inline int64_t wave2048_lds_dwords(int frames_per_wg, int hop)
+inline int64_t wave2048_lds_dwords(int frames_per_wg, int hop, bool mel = false)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 2048;
-    return 2 * span + 4 * kWave1024ScratchDwords;
+    return 2 * span + 4 * kWave1024ScratchDwords + (mel ? kMelLdsDwords : 0);
 }
-inline size_t wave2048_lds_bytes(int frames_per_wg, int hop)
+inline size_t wave2048_lds_bytes(int frames_per_wg, int hop, bool mel = false)
 {
-    return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop);
+    return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop, mel);
 }
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream);
+                           float log_floor, hipStream_t stream, const float *mel_par = nullptr,
+                           const MelSched *sched = nullptr);
 
 // ---- wave-per-4-frames 256-point kernel (onset geometry) ---------------------------
 constexpr int kWave256Rows = 50;

@@ -72,7 +72,7 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
     float p = re * re + im * im;
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower)
+    if (OUT == kPower || OUT == kLogMel)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
@@ -219,6 +219,158 @@ __device__ __forceinline__ void exchange_high(v2f (&v)[8])
         xpose_pk(v[i], v[i + 4], 2);
 }
 
+// ---- fused mel reduction (OUT == kLogMel) ---------------------------------------------
+// AA_MEL_ABL (diagnostic builds of tools/ablate_mel.sh only; 0 in the shipped library):
+// 1 no gather loops, 2 gather without its LDS reads, 4 no mel row stores, 8 no K-slice sums.
+#ifndef AA_MEL_ABL
+#define AA_MEL_ABL 0
+#endif
+// The Slaney filterbank is triangular (98 % zeros; a bin feeds at most two filters), so the fused
+// path is a gather on the VALU from the power rows the epilogue left in the wave's LDS scratch —
+// the rows never travel to HBM.  The wave's F frames get 64/F lanes each; within a frame, lane =
+// (K-slice h, mel-in-group msub).  Group g (MelSched) covers (64/F) >> part_log2[g] mels from
+// mel_base[g] and loops trips[g] bins per slice (wave-uniform; the filter width grows
+// monotonically with the mel index, so a group's filters are alike).  The weight of a filter at
+// offset i from its (host-adjusted, row-clamped) first bin is med3(U0 + i DU, D0 - i DD, 0): the
+// two edges of the triangle with the Slaney norm folded in — zero outside the support, so no
+// masks and no weight table.  Slices are summed with v_permlane32/16_swap and a DPP row_ror:8.
+// Hand-issued ds_read2_b32 (two consecutive floats at dword offset O0 from a 4-byte-aligned LDS
+// byte address) for the mel gather: the compiler would rotate the loop so that every step waits
+// for its own loads — one LDS round trip per 4 bins.  The destination is tied ("+v"): the value
+// lives in ONE register pair from issue to use, so the compiler never copies it while the load
+// is still in flight.  Valid after mel_lds_wait().
+template <int O0>
+__device__ __forceinline__ void mel_lds_read2(v2f &r, unsigned addr)
+{
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "+v"(r) : "v"(addr), "n"(O0), "n"(O0 + 1) : "memory");
+}
+template <int KEEP>   // wait until at most KEEP newer LDS operations are outstanding (LDS returns in order)
+__device__ __forceinline__ void mel_lds_wait(v2f &a, v2f &b)
+{
+    if (KEEP == 2)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
+// four bins of one filter slice: weights from the two triangle edges, accumulate
+__device__ __forceinline__ void mel_step4(float &acc, float &fi, v2f pa, v2f pb, float U0, float DU, float D0, float DD)
+{
+    const float u0 = fmaf(fi, DU, U0), d0 = fmaf(-fi, DD, D0);
+    const float u1 = u0 + DU, d1 = d0 - DD;
+    const float u2 = u1 + DU, d2 = d1 - DD;
+    const float u3 = u2 + DU, d3 = d2 - DD;
+    acc = fmaf(__builtin_amdgcn_fmed3f(u0, d0, 0.0f), pa.x, acc);
+    acc = fmaf(__builtin_amdgcn_fmed3f(u1, d1, 0.0f), pa.y, acc);
+    acc = fmaf(__builtin_amdgcn_fmed3f(u2, d2, 0.0f), pb.x, acc);
+    acc = fmaf(__builtin_amdgcn_fmed3f(u3, d3, 0.0f), pb.y, acc);
+    fi += 4.0f;
+}
+template <int F>
+__device__ __forceinline__ void mel_reduce(const float *rows, int nb, const float *par, const MelSched &sch,
+                                           float *stage)
+{
+    constexpr int LPF = 64 / F;                      // lanes per frame
+    const int lane = threadIdx.x & 63;
+    const int f = (F == 2) ? (lane >> 5) : 0;
+    int lf = lane & (LPF - 1);
+    // opaque to the optimiser: otherwise the per-group products of the lane index (loop
+    // invariant) are hoisted out of the frame loop, held across the FFT phase and spilled
+    asm volatile("" : "+v"(lf));
+    const float *row = rows + f * nb;
+    auto params_of = [&](int g) {
+        const int mi = sch.mel_base[g] + (lf & ((LPF >> sch.part_log2[g]) - 1));
+        return par + kMelParDwords * (mi < kMelMaxMels ? mi : kMelMaxMels);
+    };
+    // parameters of group 0; those of group g+1 are fetched while group g is reduced
+    const float *pm = params_of(0);
+    float K0 = pm[0], U0 = pm[1], DU = pm[2], D0 = pm[3], DD = pm[4];
+#pragma unroll
+    for (int g = 0; g < kMelMaxGroups; ++g) {
+        if (g < sch.n_groups) {
+            const int L = sch.trips[g], pl = sch.part_log2[g];
+            const int msub = lf & ((LPF >> pl) - 1), h = lf >> (F == 2 ? 5 - pl : 6 - pl);
+            const float cU0 = U0, cDU = DU, cD0 = D0, cDD = DD;
+            unsigned addr = lds_addr(row + __float_as_int(K0) + h * L);
+            if (g + 1 < kMelMaxGroups && g + 1 < sch.n_groups) {
+                const float *pn = params_of(g + 1);
+                K0 = pn[0]; U0 = pn[1]; DU = pn[2]; D0 = pn[3]; DD = pn[4];
+            }
+            float fi = (float)(h * L), acc = 0.0f;
+            // trips are multiples of 4 (host-padded): four bins per step, the next four already in
+            // flight in the other register set (A/B ping-pong, two steps per iteration); a step's
+            // prefetch may read <= 4 floats past the slice (inside the scratch, never used) and
+            // everything is drained before the registers are reused
+            v2f a0 = {0.0f, 0.0f}, a1 = a0, b0 = a0, b1 = a0;
+            if (!(AA_MEL_ABL & 3)) {
+                mel_lds_read2<0>(a0, addr);
+                mel_lds_read2<2>(a1, addr);
+            }
+            for (int i = 0; i < L && !(AA_MEL_ABL & 1); i += 8) {
+                if (!(AA_MEL_ABL & 2)) {
+                    mel_lds_read2<4>(b0, addr);
+                    mel_lds_read2<6>(b1, addr);
+                    mel_lds_wait<2>(a0, a1);
+                }
+                mel_step4(acc, fi, a0, a1, cU0, cDU, cD0, cDD);
+                if (i + 4 < L) {
+                    if (!(AA_MEL_ABL & 2)) {
+                        mel_lds_read2<8>(a0, addr);
+                        mel_lds_read2<10>(a1, addr);
+                        mel_lds_wait<2>(b0, b1);
+                    }
+                    mel_step4(acc, fi, b0, b1, cU0, cDU, cD0, cDD);
+                }
+                addr += 32;
+            }
+            mel_lds_wait<0>(a0, a1);
+            mel_lds_wait<0>(b0, b1);
+            // sum the K-slices: h sits in the top bits of the frame's lane index
+            if (pl >= 1 && !(AA_MEL_ABL & 8)) {
+                if (F == 1) {
+                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+                    acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                } else {
+                    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+                    acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+            }
+            if (pl >= 2 && !(AA_MEL_ABL & 8)) {
+                if (F == 1) {
+                    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+                    acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                } else {
+                    acc += dpp_update<0x128, 0xF>(acc, acc);   // row_ror:8: lane ^ 8 within the row
+                }
+            }
+            const int mel = sch.mel_base[g] + msub;
+            if (h == 0 && mel < kMelMaxMels)
+                stage[128 * f + mel] = acc;
+        }
+    }
+}
+// Mel values of the wave's F frames (stage[128 f + mel], written by mel_reduce) ->
+// 10 log10(max(., floor)) -> rows of n_mels floats, two coalesced dword stores per row.
+template <int F>
+__device__ __forceinline__ void mel_store(const float *stage, const MelSched &sch, float log_floor, float *row_a,
+                                          float *row_b, bool valid_b)
+{
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ff = 0; ff < F; ++ff) {
+        float *row = ff == 0 ? row_a : row_b;
+        const float v0 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(stage[128 * ff + lane], log_floor));
+        const float v1 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(stage[128 * ff + 64 + lane], log_floor));
+        if ((ff == 0 || valid_b) && !(AA_MEL_ABL & 4)) {
+            if (lane < sch.n_mels)
+                row[lane] = v0;
+            if (lane + 64 < sch.n_mels)
+                row[lane + 64] = v1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------- wave-per-frame, n_fft = 1024 --
 // One wavefront transforms one frame: the 1024 windowed reals are read as 512 complex points
 // z[m] (8 per lane), 512 = 8 x 8 x 8:
@@ -243,7 +395,7 @@ template <int OUT, int ABL = 0, bool WIDE = false>
 __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor)
+    float log_floor, const float *__restrict__ mel_par, MelSched sch)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -259,12 +411,19 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+    const int COLS = (OUT == kComplex) ? 2 * NB : (OUT == kLogMel) ? sch.n_mels : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
     float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
     int frames_left = (int)(n_frames - first_frame);                            // from chunk c on
     const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
+    // fused mel: per-mel triangle parameters in LDS behind the scratch areas (visible after the
+    // first chunk-top barrier)
+    float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
+    float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;   // mel values of the wave's frames
+    if (OUT == kLogMel)
+        for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
+            melpar[i] = mel_par[i];
 
     // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
     // (wave w moves the 1 KiB pieces w, w+4, ..)
@@ -303,7 +462,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
-        if ((ABL & 64) || c == c0 || frames_per_wg != 8)
+        if ((ABL & 64) || c == c0 || frames_per_wg != 8 || OUT == kLogMel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
@@ -377,7 +536,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                     prt[j] = v[7 - j];
             }
         };
-        auto epilogue = [&](v2f (&v)[8], v2f (&prt)[4], int t, bool valid) {
+        auto epilogue = [&](v2f (&v)[8], v2f (&prt)[4], int t, bool valid, int slot) {
             // ABL 256: all rows land in the first 32 rows of `out` (L2-resident): same store
             // instructions, no HBM write stream
             float *row = (ABL & 256) ? out + ((row0 + t) & 31) * COLS : out_chunk + t * COLS;
@@ -409,6 +568,18 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
             }
             const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+            if (OUT == kLogMel) {
+                // power row -> scratch slot (consumed by mel_reduce, never stored)
+                float *lrow = reinterpret_cast<float *>(scr) + slot * NB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lrow[lane + 64 * j] = mk[j];
+                    lrow[512 - lane - 64 * j] = mm[j];
+                }
+                if (lane == 0)
+                    lrow[256] = m256;
+                return;
+            }
             if (ABL & 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -476,8 +647,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 strip(va, pa);
                 pass_bc(vbv);
                 strip(vbv, pb);
-                epilogue(va, pa, ta, true);
-                epilogue(vbv, pb, tb, vb);
+                epilogue(va, pa, ta, true, 0);
+                epilogue(vbv, pb, tb, vb, 1);
+                if (OUT == kLogMel) {
+                    __builtin_amdgcn_wave_barrier();
+                    mel_reduce<2>(reinterpret_cast<const float *>(scr), NB, melpar, sch, melstage);
+                    mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
+                }
             }
         } else {
             for (int t = wave; t < nf; t += 4) {
@@ -488,7 +664,12 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 exchange1(v);
                 pass_bc(v);
                 strip(v, prt);
-                epilogue(v, prt, t, true);
+                epilogue(v, prt, t, true, 0);
+                if (OUT == kLogMel) {
+                    __builtin_amdgcn_wave_barrier();
+                    mel_reduce<1>(reinterpret_cast<const float *>(scr), NB, melpar, sch, melstage);
+                    mel_store<1>(melstage, sch, log_floor, out_chunk + t * COLS, nullptr, false);
+                }
             }
         }
         src_chunk += src_stride;
@@ -544,10 +725,10 @@ __device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
 }
 
 template <int OUT, bool WIDE>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave2048_kernel(
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor)
+    float log_floor, const float *__restrict__ mel_par, MelSched sch)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -559,7 +740,12 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave2048_kernel(
     const int max_span = (frames_per_wg - 1) * hop + 2048;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
-    constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
+    const int COLS = (OUT == kComplex) ? 2 * NB : (OUT == kLogMel) ? sch.n_mels : NB;
+    float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
+    float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;
+    if (OUT == kLogMel)
+        for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
+            melpar[i] = mel_par[i];
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;
     float *out_chunk = out + first_frame * COLS;
@@ -676,7 +862,19 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave2048_kernel(
                     mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
                 }
                 const float m512 = bin_value<OUT>(2.0f * z512.x, 2.0f * z512.y, log_floor);
-                if (WIDE) {
+                if (OUT == kLogMel) {
+                    float *lrow = reinterpret_cast<float *>(scr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        lrow[lane + 64 * j] = mk[j];
+                        lrow[1024 - lane - 64 * j] = mm[j];
+                    }
+                    if (lane == 0)
+                        lrow[512] = m512;
+                    __builtin_amdgcn_wave_barrier();
+                    mel_reduce<1>(lrow, NB, melpar, sch, melstage);
+                    mel_store<1>(melstage, sch, log_floor, row, nullptr, false);
+                } else if (WIDE) {
                     const int sh = (row0 + t) & 3;     // 1025 = 1 (mod 4): same shift rule as 513
                     float *lrow = reinterpret_cast<float *>(scr) + sh;
 #pragma unroll
@@ -1165,10 +1363,11 @@ static int persistent_grid(K kernel, size_t lds)
 template <int K>
 static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                                       float log_floor, hipStream_t stream)
+                                       float log_floor, hipStream_t stream, const float *mel_par,
+                                       const MelSched &sch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop);
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel);
     static int cached_grid = 0;
     static size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
@@ -1178,30 +1377,35 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
     const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
     if (wide)
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, true>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     return hipGetLastError();
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream)
+                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched)
 {
     if (n_frames <= 0)
         return hipSuccess;
+    const MelSched sch = sched ? *sched : MelSched();
+    if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
+        return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kMag:
-        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kPower:
-        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kLogPower:
-        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+    case kLogMel:
+        return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     default:
         return hipErrorInvalidValue;
     }
@@ -1210,10 +1414,11 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
 template <int K>
 static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                                       float log_floor, hipStream_t stream)
+                                       float log_floor, hipStream_t stream, const float *mel_par,
+                                       const MelSched &sch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop);
+    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop, K == kLogMel);
     static int cached_grid = 0;
     static size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
@@ -1223,29 +1428,34 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
     const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
     if (wide)
         hipLaunchKernelGGL((stft_wave2048_kernel<K, true>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else
         hipLaunchKernelGGL((stft_wave2048_kernel<K, false>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     return hipGetLastError();
 }
 
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream)
+                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched)
 {
     if (n_frames <= 0)
         return hipSuccess;
+    const MelSched sch = sched ? *sched : MelSched();
+    if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
+        return hipErrorInvalidValue;
     const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kMag:
-        return launch_wave2048_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave2048_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kPower:
-        return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kLogPower:
-        return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+    case kLogMel:
+        return launch_wave2048_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     default:
         return hipErrorInvalidValue;
     }

@@ -273,6 +273,31 @@ def test_logmel_two_channels(aa, oracle_mod, torch_mod, n, hop):
     assert np.max(np.abs(got[32760:] - L)[near]) < 1e-3
 
 
+@pytest.mark.parametrize("n,hop", [(2048, 512), (1024, 256)])
+@pytest.mark.parametrize("n_mels,fmin,fmax", [(128, 0.0, None), (80, 20.0, 8000.0), (40, 0.0, 12000.0), (100, 300.0, None), (17, 50.0, 3000.0)])
+def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, monkeypatch, n, hop, n_mels, fmin, fmax):
+    """The wave kernels reduce the power row to mel bands in LDS (triangular gather, weights from
+    the two edges of each triangle); AA_MEL_GEMM=1 selects the unfused power slab + MFMA
+    filterbank.  Both must match the float64 definition, for any band count / band edges."""
+    sr = 48000
+    x = aa.signals.synth_corpus(9, n + 777 * hop)           # ragged last chunk included
+    xd = torch_mod.from_numpy(x).cuda()
+    kw = dict(output="logmel", sample_rate=sr, n_mels=n_mels, fmin=fmin, fmax=fmax or 0.0)
+    fused = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
+    monkeypatch.setenv("AA_MEL_GEMM", "1")
+    gemm = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
+    monkeypatch.delenv("AA_MEL_GEMM")
+    tr = oracle_mod.truth
+    P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+    M = np.maximum(P @ tr.mel_filterbank(sr, n, n_mels, fmin, fmax).T, 1e-10)
+    assert fused.shape == gemm.shape == M.shape == (778, n_mels)
+    for got in (fused, gemm):
+        assert nerr(10.0 ** (got.astype(np.float64) / 10.0), M).max() < 2e-5
+    L = 10.0 * np.log10(M)
+    near = L >= L.max(axis=1, keepdims=True) - 40.0
+    assert np.max(np.abs(fused - gemm)[near]) < 1e-3
+
+
 def test_mfcc_sine_and_chirp(aa, oracle_mod, torch_mod):
     """BASELINE config 5: 40-coef MFCC (STFT -> mel -> log -> DCT-II) on a 440 Hz sine and a
     50 Hz -> 12 kHz chirp, 10 s.  tol 1e-5 max-normalised per frame vs the float64 definition.

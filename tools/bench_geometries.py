@@ -10,14 +10,24 @@ import torch
 
 import audio_analyzer_rs_amd as aa
 
+if os.environ.get("AA_LIB_OVERRIDE"):      # diagnostic builds of tools/ablate_mel.sh
+    aa._lib.LIB_PATH = os.path.abspath(os.environ["AA_LIB_OVERRIDE"])
+
 x = aa.signals.synth_corpus(0, 28_800_000)
 xd = torch.from_numpy(x).cuda()
 cases = [
     (1024, 256, "mag", {}), (1024, 256, "complex", {}), (2048, 512, "mag", {}), (2048, 512, "complex", {}),
     (256, 64, "mag", {}), (512, 128, "mag", {}), (4096, 1024, "mag", {}),
-    (2048, 512, "logmel", dict(n_mels=128)), (1024, 256, "mfcc", dict(n_mels=128, n_mfcc=40)),
+    (2048, 512, "logmel", dict(n_mels=128)), (1024, 256, "logmel", dict(n_mels=128)),
+    (1024, 256, "mfcc", dict(n_mels=128, n_mfcc=40)),
+    (2048, 512, "logmel", dict(n_mels=128, gemm=1)), (1024, 256, "mfcc", dict(n_mels=128, n_mfcc=40, gemm=1)),
 ]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if c[2] in sys.argv[1:]]
 for n, hop, outk, kw in cases:
+    kw = dict(kw)
+    gemm = kw.pop("gemm", 0)
+    os.environ["AA_MEL_GEMM"] = str(gemm)     # 1: unfused slab + MFMA GEMM filterbank
     plan = aa.Stft(n, hop, output=outk, **kw)
     nf = plan.num_frames(xd.shape[0])
     out = torch.empty((nf, plan.cols), dtype=torch.float32, device="cuda")
@@ -35,5 +45,5 @@ for n, hop, outk, kw in cases:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     bpf = hop * 4 + plan.cols * 4
-    print(f"n_fft {n:5d} hop {hop:5d} {outk:8s} kernel {plan.kernel:10s} {nf:7d} frames  {ms*1e3:9.1f} us  "
+    print(f"n_fft {n:5d} hop {hop:5d} {(outk + ('/gemm' if gemm else '')):11s} kernel {plan.kernel:10s} {nf:7d} frames  {ms*1e3:9.1f} us  "
           f"{nf/ms*1e3:10.4g} frames/s  {bpf} B/frame  {nf*bpf/ms/1e6/8000:6.3f} of 8 TB/s")
