@@ -462,8 +462,15 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
-        if ((ABL & 64) || c == c0 || frames_per_wg != 8 || OUT == kLogMel)
+        // The DMA loads of this chunk were issued before the previous chunk's row stores, and
+        // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
+        // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
+        if ((ABL & 64) || c == c0 || frames_per_wg != 8)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (OUT == kLogMel && sch.n_mels > 64)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // 2 dword stores per mel row
+        else if (OUT == kLogMel)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
@@ -788,7 +795,16 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
+        // row in the previous (full) chunk, after issuing this chunk's DMA loads
+        if (c == c0 || frames_per_wg != 4 || OUT == kComplex || (OUT != kLogMel && !WIDE))
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (OUT == kLogMel && sch.n_mels > 64)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (OUT == kLogMel)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // 4 dwordx4 pieces + head/tail dwords
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
@@ -1017,7 +1033,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // counted wait as in stft_wave1024_kernel: with 32 frames per chunk every wave stored
+        // two 4-frame groups (3 stores each) in the previous (full) chunk, after issuing this
+        // chunk's DMA loads
+        if (c == c0 || frames_per_wg != 32 || OUT == kComplex || !WIDE)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
