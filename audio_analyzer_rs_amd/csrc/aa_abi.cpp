@@ -182,6 +182,55 @@ void mel_filterbank(int sr, int n_fft, int n_mels, double fmin, double fmax, std
     }
 }
 
+// Cuts n_mels filters of widths len[] into <= kMelMaxGroups groups of (lanes >> pl) consecutive
+// mels with 1 << pl K-slices each (pl = 0, 1, 2): a small dynamic programme minimising
+// sum(bins per slice + per-group overhead).  Fills n_mels / n_groups / trips / mel_base /
+// part_log2 of *sch.  overhead_bins: cost of one more group in units of bins per slice.
+bool plan_mel_groups(const std::vector<int> &len, int n_mels, int lanes, int nb, int overhead_bins,
+                     aa::MelSched *sch)
+{
+    auto trips_of = [&](int first, int pl) {
+        int widest = 0;
+        for (int m = first; m < std::min(n_mels, first + (lanes >> pl)); ++m)
+            widest = std::max(widest, len[m]);
+        return ((widest + (1 << pl) - 1) / (1 << pl) + 3) / 4 * 4;   // the kernels step 4 bins at a time
+    };
+    // best[j][m]: cheapest way to cover mels [m, n_mels) with exactly j more groups
+    const int G = aa::kMelMaxGroups, kOverhead = overhead_bins, kInf = 1 << 28;
+    std::vector<std::vector<int>> best(G + 1, std::vector<int>(n_mels + 1, kInf)), pick = best;
+    best[0][n_mels] = 0;
+    for (int j = 1; j <= G; ++j)
+        for (int m = n_mels - 1; m >= 0; --m)
+            for (int pl = 0; pl <= 2; ++pl) {
+                const int next = std::min(n_mels, m + (lanes >> pl));
+                const int t = trips_of(m, pl);
+                if ((t << pl) > nb || best[j - 1][next] >= kInf)
+                    continue;
+                const int cost = best[j - 1][next] + std::max(t, 4) + kOverhead;
+                if (cost < best[j][m]) {
+                    best[j][m] = cost;
+                    pick[j][m] = pl;
+                }
+            }
+    int jbest = 0;
+    for (int j = 1; j <= G; ++j)
+        if (best[j][0] < (jbest ? best[jbest][0] : kInf))
+            jbest = j;
+    if (!jbest)
+        return false;
+    *sch = aa::MelSched();
+    sch->n_mels = n_mels;
+    sch->n_groups = jbest;
+    for (int g = 0, m = 0, j = jbest; j > 0; ++g, --j) {
+        const int pl = pick[j][m];
+        sch->trips[g] = std::max(trips_of(m, pl), 4);
+        sch->mel_base[g] = m;
+        sch->part_log2[g] = pl;
+        m = std::min(n_mels, m + (lanes >> pl));
+    }
+    return true;
+}
+
 // Parameters and schedule of the fused mel reduction (aa_internal.hpp: MelSched): the same Slaney
 // triangles as mel_filterbank, as two lines per filter in bin units.  `lanes` lanes reduce one
 // frame (64 at n_fft 2048, 32 at 1024).  The mels are cut into <= kMelMaxGroups groups of
@@ -207,45 +256,12 @@ bool build_mel_sched(int sr, int n_fft, int n_mels, double fmin, double fmax, in
         const int k_hi = std::min(nb - 1, (int)std::ceil(c[m + 2]) - 1);      // last  k < c[m+2]
         len[m] = std::max(0, k_hi - k_lo[m] + 1);
     }
-    auto trips_of = [&](int first, int pl) {
-        int widest = 0;
-        for (int m = first; m < std::min(n_mels, first + (lanes >> pl)); ++m)
-            widest = std::max(widest, len[m]);
-        return ((widest + (1 << pl) - 1) / (1 << pl) + 3) / 4 * 4;   // the kernel steps 4 bins at a time
-    };
-    // best[j][m]: cheapest way to cover mels [m, n_mels) with exactly j more groups
-    const int G = aa::kMelMaxGroups, kOverhead = 8, kInf = 1 << 28;
-    std::vector<std::vector<int>> best(G + 1, std::vector<int>(n_mels + 1, kInf)), pick = best;
-    best[0][n_mels] = 0;
-    for (int j = 1; j <= G; ++j)
-        for (int m = n_mels - 1; m >= 0; --m)
-            for (int pl = 0; pl <= 2; ++pl) {
-                const int next = std::min(n_mels, m + (lanes >> pl));
-                const int t = trips_of(m, pl);
-                if ((t << pl) > nb || best[j - 1][next] >= kInf)
-                    continue;
-                const int cost = best[j - 1][next] + t + kOverhead;
-                if (cost < best[j][m]) {
-                    best[j][m] = cost;
-                    pick[j][m] = pl;
-                }
-            }
-    int jbest = 0;
-    for (int j = 1; j <= G; ++j)
-        if (best[j][0] < (jbest ? best[jbest][0] : kInf))
-            jbest = j;
-    if (!jbest)
+    if (!plan_mel_groups(len, n_mels, lanes, nb, 8, sch))
         return false;
     par->assign(aa::kMelParTableDwords, 0.0f);
-    *sch = aa::MelSched();
-    sch->n_mels = n_mels;
-    sch->n_groups = jbest;
-    for (int g = 0, m = 0, j = jbest; j > 0; ++g, --j) {
-        const int pl = pick[j][m], parts = 1 << pl, trips = trips_of(m, pl);
+    for (int g = 0; g < sch->n_groups; ++g) {
+        const int m = sch->mel_base[g], pl = sch->part_log2[g], parts = 1 << pl, trips = sch->trips[g];
         const int next = std::min(n_mels, m + (lanes >> pl));
-        sch->trips[g] = trips;
-        sch->mel_base[g] = m;
-        sch->part_log2[g] = pl;
         for (int i = m; i < next; ++i) {
             const int ks = std::max(0, std::min(k_lo[i], nb - parts * trips));
             const double e = 2.0 / (hz[i + 2] - hz[i]);
@@ -257,7 +273,60 @@ bool build_mel_sched(int sr, int n_fft, int n_mels, double fmin, double fmax, in
             q[3] = (float)(e * (c[i + 2] - (double)ks) * id);
             q[4] = (float)(e * id);
         }
-        m = next;
+    }
+    return true;
+}
+
+// kLogMelR (aa_internal.hpp): schedule over all 64 lanes + the per-lane table of resident
+// weights, taken from the dense float64 filterbank `w` [n_mels][nb] (so the values are those
+// of the GEMM path).  Fails when the schedule needs more than kMelResidentSteps steps.
+bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab,
+                        aa::MelSched *sch)
+{
+    if (n_mels < 1 || n_mels > aa::kMelMaxMels)
+        return false;
+    std::vector<int> lo(n_mels, 0), len(n_mels, 0);
+    for (int m = 0; m < n_mels; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (w[(size_t)m * nb + k] != 0.0) {
+                if (first < 0)
+                    first = k;
+                last = k;
+            }
+        if (first >= 0) {
+            lo[m] = first;
+            len[m] = last - first + 1;
+        }
+    }
+    // a group's end costs about one 4-bin step here; fewer steps = fewer registers
+    if (!plan_mel_groups(len, n_mels, 64, nb, 4, sch))
+        return false;
+    int steps = 0;
+    for (int g = 0; g < sch->n_groups; ++g)
+        steps += sch->trips[g] / 4;
+    if (steps < 1 || steps > aa::kMelResidentSteps)
+        return false;
+    sch->n_steps = steps;
+    tab->assign(aa::kMelResidentTableDwords, 0.0f);
+    int s = 0;
+    for (int g = 0; g < sch->n_groups; ++g) {
+        const int pl = sch->part_log2[g], parts = 1 << pl, trips = sch->trips[g], base = sch->mel_base[g];
+        for (int t = 0; t < trips / 4; ++t, ++s) {
+            sch->step_info[s] = (t == trips / 4 - 1 ? 1 : 0) | (pl << 1) | (base << 4);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int msub = lane & ((64 >> pl) - 1), h = lane >> (6 - pl), mel = base + msub;
+                if (mel >= n_mels)
+                    continue;   // weights 0, offset 0
+                const int ks = std::max(0, std::min(lo[mel], nb - parts * trips));
+                const int k0 = ks + h * trips + 4 * t;
+                for (int j = 0; j < 4; ++j)
+                    (*tab)[(size_t)(s * 5 + j) * 64 + lane] =
+                        k0 + j < nb ? (float)w[(size_t)mel * nb + k0 + j] : 0.0f;
+                const unsigned off = 4u * (unsigned)k0;
+                std::memcpy(&(*tab)[(size_t)(s * 5 + 4) * 64 + lane], &off, sizeof(unsigned));
+            }
+        }
     }
     return true;
 }
@@ -366,7 +435,8 @@ struct aa_stft_plan {
     int64_t ws_logmel_rows = 0;
     // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
     bool fused_mel = false;
-    float *d_mel_par = nullptr;    // [kMelParTableDwords]
+    bool mel_resident = false;     // 1024 kernel with the weights resident in registers (kLogMelR)
+    float *d_mel_par = nullptr;    // [kMelParTableDwords] or [kMelResidentTableDwords]
     aa::MelSched mel_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
     hipStream_t pipe_stream[2] = {nullptr, nullptr};
@@ -688,8 +758,17 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             const bool mel_lds_ok =
                 (p->wave2048 ? aa::wave2048_lds_dwords(p->frames_per_wg, cfg->hop, true)
                              : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384;
-            if (mel_lds_ok && build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes,
-                                              &par, &p->mel_sched)) {
+            const char *no_res = std::getenv("AA_MEL_NO_RESIDENT");
+            bool ok = false;
+            if (mel_lds_ok && p->wave1024 && !(no_res && std::atoi(no_res) != 0)) {
+                std::vector<double> w;
+                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
+                ok = p->mel_resident = build_mel_resident(w, nb, cfg->n_mels, &par, &p->mel_sched);
+            }
+            if (!ok && mel_lds_ok)
+                ok = build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes, &par,
+                                     &p->mel_sched);
+            if (ok) {
                 AA_HIP(hipMalloc(&p->d_mel_par, par.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_mel_par, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
                 p->fused_mel = true;
@@ -801,7 +880,8 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
                 AA_HIP(aa::launch_wave2048(aa::kLogMel, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
             else
-                AA_HIP(aa::launch_wave1024(aa::kLogMel, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                AA_HIP(aa::launch_wave1024(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
+                                           p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
             return AA_OK;
         };

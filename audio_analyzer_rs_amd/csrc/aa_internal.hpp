@@ -9,7 +9,7 @@ namespace aa {
 
 // Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
 // the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
-enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4 };
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5 };
 
 // ---- fused mel reduction (wave kernels, kLogMel) ------------------------------------
 // The filterbank is triangular: 98 % zeros, every bin feeds at most two filters, so the fused
@@ -34,7 +34,16 @@ struct MelSched {
     int trips[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};       // bins per K-slice (multiples of 4)
     int mel_base[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};
     int part_log2[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0, 1 or 2
+    // kLogMelR only: the groups flattened into n_steps 4-bin steps;
+    // step_info[s] = last step of its group (bit 0) | part_log2 << 1 | mel_base << 4
+    int n_steps = 0;
+    int step_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+// kLogMelR (1024 kernel, weights resident in registers): the schedule must fit kMelResidentSteps
+// steps of 4 bins; per-lane table [kMelResidentSteps][5][64]: 4 weights + the byte offset of the
+// step's first bin in the power row.
+constexpr int kMelResidentSteps = 8;
+constexpr int kMelResidentTableDwords = kMelResidentSteps * 5 * 64;
 
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see

@@ -72,7 +72,7 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
     float p = re * re + im * im;
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
@@ -244,6 +244,15 @@ __device__ __forceinline__ void mel_lds_read2(v2f &r, unsigned addr)
 {
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "+v"(r) : "v"(addr), "n"(O0), "n"(O0 + 1) : "memory");
 }
+// Same with a fresh (untied) destination, for straight-line code where every load has its own
+// variable: no copy of a previous value is ever needed.
+template <int O0>
+__device__ __forceinline__ v2f mel_lds_load2(unsigned addr)
+{
+    v2f r;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O0 + 1) : "memory");
+    return r;
+}
 template <int KEEP>   // wait until at most KEEP newer LDS operations are outstanding (LDS returns in order)
 __device__ __forceinline__ void mel_lds_wait(v2f &a, v2f &b)
 {
@@ -348,6 +357,111 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
         }
     }
 }
+// kLogMelR (1024 kernel): the same reduction with the filter weights RESIDENT IN REGISTERS.  The
+// weights of a (lane, step) do not depend on the frame, and a persistent workgroup transforms
+// ~100 frames: computing them per frame (mel_reduce) costs more than the gather itself.  All 64
+// lanes are (K-slice, mel-in-group) for BOTH frames of the wave (rows a and b, 2052 bytes
+// apart), the groups are flattened into <= kMelResidentSteps steps of 4 bins; a lane keeps 4
+// weights (the float64 filterbank rounded to f32 — the very values of the GEMM path) and the
+// byte offset of its 4 bins per step: 40 VGPRs for the kernel's lifetime.
+struct MelResident {
+    float w[kMelResidentSteps][4];
+    unsigned off[kMelResidentSteps];
+};
+__device__ __forceinline__ void mel_resident_load(MelResident &mr, const float *tab)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < kMelResidentSteps; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            mr.w[s][j] = tab[(s * 5 + j) * 64 + lane];
+        mr.off[s] = __float_as_uint(tab[(s * 5 + 4) * 64 + lane]);
+    }
+}
+template <int KEEP>   // wait until at most KEEP newer LDS operations are outstanding
+__device__ __forceinline__ void mel_lds_wait4(v2f &a, v2f &b, v2f &c, v2f &d)
+{
+    if (KEEP == 8)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    else if (KEEP == 4)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident &mr, const MelSched &sch,
+                                                    float *stage)
+{
+    constexpr int NS = kMelResidentSteps;
+    constexpr unsigned kRowB = 513 * 4;              // row b = row a + 513 floats
+    const int lane = threadIdx.x & 63;
+    // Phase 1 - straight-line code, no branch: the compiler treats the result of a hand-issued
+    // load as available at once, so nothing it could turn into a register copy (a branch merge,
+    // a tied operand it cannot coalesce) may sit between an issue and its wait.  All
+    // kMelResidentSteps steps always run (unused steps carry zero weights); every step has its own
+    // registers {row a bins 0-1, 2-3, row b bins 0-1, 2-3}, the loads of three steps are in flight
+    // (the phase is bound by the LDS round trip, not by its 64 FMAs); every step leaves its
+    // partial sums in ra[s] / rb[s].
+    v2f P[NS][4];
+    auto issue = [&](int s) {
+        const unsigned aa = rows_addr + mr.off[s], ab = aa + kRowB;
+        P[s][0] = mel_lds_load2<0>(aa);
+        P[s][1] = mel_lds_load2<2>(aa);
+        P[s][2] = mel_lds_load2<0>(ab);
+        P[s][3] = mel_lds_load2<2>(ab);
+    };
+    float ra[NS], rb[NS];
+    issue(0);
+    issue(1);
+    issue(2);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        v2f(&c)[4] = P[s];
+        if (s + 2 < NS)
+            mel_lds_wait4<8>(c[0], c[1], c[2], c[3]);
+        else if (s + 1 < NS)
+            mel_lds_wait4<4>(c[0], c[1], c[2], c[3]);
+        else
+            mel_lds_wait4<0>(c[0], c[1], c[2], c[3]);
+        ra[s] = fmaf(mr.w[s][3], c[1].y, fmaf(mr.w[s][2], c[1].x, fmaf(mr.w[s][1], c[0].y, mr.w[s][0] * c[0].x)));
+        rb[s] = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, mr.w[s][0] * c[2].x)));
+        // keep the step's FMAs here (its four registers die, the next issue reuses them):
+        // otherwise all eight steps' loads are hoisted and 64 VGPRs of bins stay live
+        asm volatile("" : "+v"(ra[s]), "+v"(rb[s]));
+        if (s + 3 < NS)
+            issue(s + 3 < NS ? s + 3 : s);
+    }
+    // Phase 2 - everything has arrived: add the steps of each group, sum its K-slices, emit
+    float acc_a = 0.0f, acc_b = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc_a += ra[s];
+        acc_b += rb[s];
+        const int info = sch.step_info[s];
+        if (info & 1) {                              // last step of a group
+            const int pl = (info >> 1) & 7, base = info >> 4;
+            if (pl >= 1) {
+                auto xa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
+                acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
+                auto xb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
+                acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+            }
+            if (pl >= 2) {
+                auto xa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
+                acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
+                auto xb = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
+                acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+            }
+            const int mel = base + (lane & ((64 >> pl) - 1));
+            if ((lane >> (6 - pl)) == 0 && mel < kMelMaxMels) {
+                stage[mel] = acc_a;
+                stage[128 + mel] = acc_b;
+            }
+            acc_a = 0.0f;
+            acc_b = 0.0f;
+        }
+    }
+}
 // Mel values of the wave's F frames (stage[128 f + mel], written by mel_reduce) ->
 // 10 log10(max(., floor)) -> rows of n_mels floats, two coalesced dword stores per row.
 template <int F>
@@ -411,7 +525,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
-    const int COLS = (OUT == kComplex) ? 2 * NB : (OUT == kLogMel) ? sch.n_mels : NB;
+    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
     float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
@@ -424,6 +539,9 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
+    MelResident mres;
+    if (OUT == kLogMelR)
+        mel_resident_load(mres, mel_par);
 
     // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
     // (wave w moves the 1 KiB pieces w, w+4, ..)
@@ -467,9 +585,9 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
         if ((ABL & 64) || c == c0 || frames_per_wg != 8)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (OUT == kLogMel && sch.n_mels > 64)
+        else if (MEL && sch.n_mels > 64)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // 2 dword stores per mel row
-        else if (OUT == kLogMel)
+        else if (MEL)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
@@ -575,7 +693,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
             }
             const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
-            if (OUT == kLogMel) {
+            if (MEL) {
                 // power row -> scratch slot (consumed by mel_reduce, never stored)
                 float *lrow = reinterpret_cast<float *>(scr) + slot * NB;
 #pragma unroll
@@ -659,6 +777,10 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 if (OUT == kLogMel) {
                     __builtin_amdgcn_wave_barrier();
                     mel_reduce<2>(reinterpret_cast<const float *>(scr), NB, melpar, sch, melstage);
+                    mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
+                } else if (OUT == kLogMelR) {
+                    __builtin_amdgcn_wave_barrier();
+                    mel_reduce_resident(lds_addr(scr), mres, sch, melstage);
                     mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
                 }
             }
@@ -1389,7 +1511,7 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
                                        const MelSched &sch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel);
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
     static int cached_grid = 0;
     static size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
@@ -1415,6 +1537,8 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
+    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps || frames_per_wg != 8))
+        return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
@@ -1428,6 +1552,8 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
         return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kLogMel:
         return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+    case kLogMelR:
+        return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     default:
         return hipErrorInvalidValue;
     }
