@@ -279,9 +279,9 @@ bool build_mel_sched(int sr, int n_fft, int n_mels, double fmin, double fmax, in
 
 // kLogMelR (aa_internal.hpp): schedule over all 64 lanes + the per-lane table of resident
 // weights, taken from the dense float64 filterbank `w` [n_mels][nb] (so the values are those
-// of the GEMM path).  Fails when the schedule needs more than kMelResidentSteps steps.
-bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab,
-                        aa::MelSched *sch)
+// of the GEMM path).  Fails when the schedule needs more than max_steps steps.
+bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, int max_steps,
+                        std::vector<float> *tab, aa::MelSched *sch)
 {
     if (n_mels < 1 || n_mels > aa::kMelMaxMels)
         return false;
@@ -305,7 +305,7 @@ bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, std::v
     int steps = 0;
     for (int g = 0; g < sch->n_groups; ++g)
         steps += sch->trips[g] / 4;
-    if (steps < 1 || steps > aa::kMelResidentSteps)
+    if (steps < 1 || steps > max_steps)
         return false;
     sch->n_steps = steps;
     tab->assign(aa::kMelResidentTableDwords, 0.0f);
@@ -435,7 +435,7 @@ struct aa_stft_plan {
     int64_t ws_logmel_rows = 0;
     // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
     bool fused_mel = false;
-    bool mel_resident = false;     // 1024 kernel with the weights resident in registers (kLogMelR)
+    bool mel_resident = false;     // 1024 kernel with the filter weights resident in registers (kLogMelR)
     float *d_mel_par = nullptr;    // [kMelParTableDwords] or [kMelResidentTableDwords]
     aa::MelSched mel_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
@@ -760,10 +760,11 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                              : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384;
             const char *no_res = std::getenv("AA_MEL_NO_RESIDENT");
             bool ok = false;
-            if (mel_lds_ok && p->wave1024 && !(no_res && std::atoi(no_res) != 0)) {
+            if (mel_lds_ok && !(no_res && std::atoi(no_res) != 0) && p->wave1024) {
                 std::vector<double> w;
                 mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
-                ok = p->mel_resident = build_mel_resident(w, nb, cfg->n_mels, &par, &p->mel_sched);
+                ok = p->mel_resident =
+                    build_mel_resident(w, nb, cfg->n_mels, aa::kMelResidentSteps1024, &par, &p->mel_sched);
             }
             if (!ok && mel_lds_ok)
                 ok = build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes, &par,

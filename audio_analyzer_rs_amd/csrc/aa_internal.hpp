@@ -39,11 +39,11 @@ struct MelSched {
     int n_steps = 0;
     int step_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
-// kLogMelR (1024 kernel, weights resident in registers): the schedule must fit kMelResidentSteps
-// steps of 4 bins; per-lane table [kMelResidentSteps][5][64]: 4 weights + the byte offset of the
-// step's first bin in the power row.
-constexpr int kMelResidentSteps = 8;
-constexpr int kMelResidentTableDwords = kMelResidentSteps * 5 * 64;
+// kLogMelR (1024 kernel, weights resident in registers): the schedule must fit
+// kMelResidentSteps1024 steps of 4 bins (36 VGPRs); per-lane table [steps][5][64]: 4 weights + the
+// byte offset of the step's first bin in the power row (< 65536; the kernel packs two per register).
+constexpr int kMelResidentSteps1024 = 8;
+constexpr int kMelResidentTableDwords = kMelResidentSteps1024 * 5 * 64;
 
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see

@@ -357,79 +357,108 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
         }
     }
 }
-// kLogMelR (1024 kernel): the same reduction with the filter weights RESIDENT IN REGISTERS.  The
-// weights of a (lane, step) do not depend on the frame, and a persistent workgroup transforms
-// ~100 frames: computing them per frame (mel_reduce) costs more than the gather itself.  All 64
-// lanes are (K-slice, mel-in-group) for BOTH frames of the wave (rows a and b, 2052 bytes
-// apart), the groups are flattened into <= kMelResidentSteps steps of 4 bins; a lane keeps 4
-// weights (the float64 filterbank rounded to f32 — the very values of the GEMM path) and the
-// byte offset of its 4 bins per step: 40 VGPRs for the kernel's lifetime.
+// kLogMelR: the same reduction with the filter weights RESIDENT IN REGISTERS.  The weights of a
+// (lane, step) do not depend on the frame, and a persistent workgroup transforms ~100 frames:
+// computing them per frame (mel_reduce) costs more than the gather itself.  All 64 lanes are
+// (K-slice, mel-in-group) — at 1024 (F = 2) for BOTH frames of the wave (rows a and b, 2052 bytes
+// apart) — and the groups are flattened into <= NS steps of 4 bins; a lane keeps 4 weights (the
+// float64 filterbank rounded to f32 — the very values of the GEMM path) and the byte offset of
+// its 4 bins per step (two packed per register): 36 VGPRs at NS = 8 for the kernel's lifetime.
+// (Tried at 2048 with F = 1, NS = 14: 63 more VGPRs push that kernel to two waves per SIMD and
+// the FFT phase loses what the gather gains — 126 us either way — so 2048 keeps mel_reduce.)
+template <int NS>
 struct MelResident {
-    float w[kMelResidentSteps][4];
-    unsigned off[kMelResidentSteps];
+    float w[NS][4];
+    unsigned off2[(NS + 1) / 2];   // two 16-bit byte offsets per register
+    __device__ __forceinline__ unsigned off(int s) const { return (s & 1) ? off2[s >> 1] >> 16 : off2[s >> 1] & 0xffffu; }
 };
-__device__ __forceinline__ void mel_resident_load(MelResident &mr, const float *tab)
+template <int NS>
+__device__ __forceinline__ void mel_resident_load(MelResident<NS> &mr, const float *tab)
 {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int s = 0; s < kMelResidentSteps; ++s) {
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             mr.w[s][j] = tab[(s * 5 + j) * 64 + lane];
-        mr.off[s] = __float_as_uint(tab[(s * 5 + 4) * 64 + lane]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s += 2) {
+        const unsigned lo = __float_as_uint(tab[(s * 5 + 4) * 64 + lane]);
+        const unsigned hi = s + 1 < NS ? __float_as_uint(tab[((s + 1 < NS ? s + 1 : s) * 5 + 4) * 64 + lane]) : 0u;
+        mr.off2[s >> 1] = lo | (hi << 16);
     }
 }
-template <int KEEP>   // wait until at most KEEP newer LDS operations are outstanding
-__device__ __forceinline__ void mel_lds_wait4(v2f &a, v2f &b, v2f &c, v2f &d)
+template <int KEEP, int F>   // wait until at most KEEP newer LDS operations are outstanding
+__device__ __forceinline__ void mel_lds_wait_step(v2f (&c)[4])
 {
-    if (KEEP == 8)
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-    else if (KEEP == 4)
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+    if (F == 2)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(KEEP) : "memory");
     else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(KEEP) : "memory");
 }
-__device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident &mr, const MelSched &sch,
-                                                    float *stage)
+template <int NS, int F>
+__device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident<NS> &mr,
+                                                    const MelSched &sch, float *stage)
 {
-    constexpr int NS = kMelResidentSteps;
-    constexpr unsigned kRowB = 513 * 4;              // row b = row a + 513 floats
+    constexpr unsigned kRowB = 513 * 4;              // F == 2 (1024): row b = row a + 513 floats
+    constexpr int LPS = 2 * F;                       // ds_read2_b32 per step
+    constexpr int D = 12 / LPS;                      // steps in flight (<= 12 loads; lgkmcnt counts to 15)
     const int lane = threadIdx.x & 63;
+    // opaque: keeps the NS (2 NS) per-step addresses from being hoisted out of the frame loop
+    // into as many long-lived VGPRs
+    asm volatile("" : "+v"(rows_addr));
     // Phase 1 - straight-line code, no branch: the compiler treats the result of a hand-issued
     // load as available at once, so nothing it could turn into a register copy (a branch merge,
-    // a tied operand it cannot coalesce) may sit between an issue and its wait.  All
-    // kMelResidentSteps steps always run (unused steps carry zero weights); every step has its own
-    // registers {row a bins 0-1, 2-3, row b bins 0-1, 2-3}, the loads of three steps are in flight
-    // (the phase is bound by the LDS round trip, not by its 64 FMAs); every step leaves its
-    // partial sums in ra[s] / rb[s].
+    // a tied operand it cannot coalesce) may sit between an issue and its wait.  All NS steps
+    // always run (unused steps carry zero weights); every step has its own registers {row a
+    // bins 0-1, 2-3 [, row b bins 0-1, 2-3]}, the loads of D steps are in flight (the phase is
+    // bound by the LDS round trip, not by its FMAs); a step leaves its partial sums in ra / rb.
     v2f P[NS][4];
     auto issue = [&](int s) {
-        const unsigned aa = rows_addr + mr.off[s], ab = aa + kRowB;
+        const unsigned aa = rows_addr + mr.off(s);
         P[s][0] = mel_lds_load2<0>(aa);
         P[s][1] = mel_lds_load2<2>(aa);
-        P[s][2] = mel_lds_load2<0>(ab);
-        P[s][3] = mel_lds_load2<2>(ab);
+        if (F == 2) {
+            P[s][2] = mel_lds_load2<0>(aa + kRowB);
+            P[s][3] = mel_lds_load2<2>(aa + kRowB);
+        }
     };
     float ra[NS], rb[NS];
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int s = 0; s < D && s < NS; ++s)
+        issue(s);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         v2f(&c)[4] = P[s];
-        if (s + 2 < NS)
-            mel_lds_wait4<8>(c[0], c[1], c[2], c[3]);
-        else if (s + 1 < NS)
-            mel_lds_wait4<4>(c[0], c[1], c[2], c[3]);
+        constexpr int kMax = (D - 1) * LPS;
+        const int newer = (NS - 1 - s) * LPS;        // loads issued after this step's
+        if (newer >= kMax)
+            mel_lds_wait_step<kMax, F>(c);
+        else if (newer == 10)
+            mel_lds_wait_step<10, F>(c);
+        else if (newer == 8)
+            mel_lds_wait_step<8, F>(c);
+        else if (newer == 6)
+            mel_lds_wait_step<6, F>(c);
+        else if (newer == 4)
+            mel_lds_wait_step<4, F>(c);
+        else if (newer == 2)
+            mel_lds_wait_step<2, F>(c);
         else
-            mel_lds_wait4<0>(c[0], c[1], c[2], c[3]);
+            mel_lds_wait_step<0, F>(c);
         ra[s] = fmaf(mr.w[s][3], c[1].y, fmaf(mr.w[s][2], c[1].x, fmaf(mr.w[s][1], c[0].y, mr.w[s][0] * c[0].x)));
-        rb[s] = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, mr.w[s][0] * c[2].x)));
-        // keep the step's FMAs here (its four registers die, the next issue reuses them):
-        // otherwise all eight steps' loads are hoisted and 64 VGPRs of bins stay live
-        asm volatile("" : "+v"(ra[s]), "+v"(rb[s]));
-        if (s + 3 < NS)
-            issue(s + 3 < NS ? s + 3 : s);
+        rb[s] = 0.0f;
+        if (F == 2)
+            rb[s] = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, mr.w[s][0] * c[2].x)));
+        // keep the step's FMAs here (its registers die, the next issue reuses them): otherwise
+        // all steps' loads are hoisted and their bins stay live
+        if (F == 2)
+            asm volatile("" : "+v"(ra[s]), "+v"(rb[s]));
+        else
+            asm volatile("" : "+v"(ra[s]));
+        if (s + D < NS)
+            issue(s + D < NS ? s + D : s);
     }
     // Phase 2 - everything has arrived: add the steps of each group, sum its K-slices, emit
     float acc_a = 0.0f, acc_b = 0.0f;
@@ -443,19 +472,24 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
             if (pl >= 1) {
                 auto xa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
                 acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-                auto xb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
-                acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+                if (F == 2) {
+                    auto xb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
+                    acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+                }
             }
             if (pl >= 2) {
                 auto xa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
                 acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-                auto xb = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
-                acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+                if (F == 2) {
+                    auto xb = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
+                    acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
+                }
             }
             const int mel = base + (lane & ((64 >> pl) - 1));
             if ((lane >> (6 - pl)) == 0 && mel < kMelMaxMels) {
                 stage[mel] = acc_a;
-                stage[128 + mel] = acc_b;
+                if (F == 2)
+                    stage[128 + mel] = acc_b;
             }
             acc_a = 0.0f;
             acc_b = 0.0f;
@@ -539,7 +573,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
-    MelResident mres;
+    MelResident<kMelResidentSteps1024> mres;
     if (OUT == kLogMelR)
         mel_resident_load(mres, mel_par);
 
@@ -780,7 +814,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                     mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
                 } else if (OUT == kLogMelR) {
                     __builtin_amdgcn_wave_barrier();
-                    mel_reduce_resident(lds_addr(scr), mres, sch, melstage);
+                    mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, melstage);
                     mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
                 }
             }
@@ -869,12 +903,14 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
     const int max_span = (frames_per_wg - 1) * hop + 2048;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
-    const int COLS = (OUT == kComplex) ? 2 * NB : (OUT == kLogMel) ? sch.n_mels : NB;
+    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
     float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
+
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;
     float *out_chunk = out + first_frame * COLS;
@@ -919,11 +955,11 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
         const int cur = (c - c0) & 1;
         // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
         // row in the previous (full) chunk, after issuing this chunk's DMA loads
-        if (c == c0 || frames_per_wg != 4 || OUT == kComplex || (OUT != kLogMel && !WIDE))
+        if (c == c0 || frames_per_wg != 4 || OUT == kComplex || (!MEL && !WIDE))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (OUT == kLogMel && sch.n_mels > 64)
+        else if (MEL && sch.n_mels > 64)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (OUT == kLogMel)
+        else if (MEL)
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // 4 dwordx4 pieces + head/tail dwords
@@ -1000,7 +1036,7 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                     mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
                 }
                 const float m512 = bin_value<OUT>(2.0f * z512.x, 2.0f * z512.y, log_floor);
-                if (OUT == kLogMel) {
+                if (MEL) {
                     float *lrow = reinterpret_cast<float *>(scr);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -1537,7 +1573,7 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
-    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps || frames_per_wg != 8))
+    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
         return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
@@ -1566,7 +1602,7 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
                                        const MelSched &sch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop, K == kLogMel);
+    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
     static int cached_grid = 0;
     static size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
