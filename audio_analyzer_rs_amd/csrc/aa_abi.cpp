@@ -1054,6 +1054,24 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
     return AA_OK;
 }
 
+int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bins, const float *flux_dev,
+                          const float *energy_dev, const float *global_floor_dev, float *state_dev,
+                          int32_t initialized, float *out_flux_dev, float *out_ema_dev,
+                          float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                          float *out_velocity_dev, void *stream)
+{
+    if (!mags_dev || !flux_dev || !energy_dev || !global_floor_dev || !state_dev || !out_flux_dev ||
+        !out_ema_dev || !out_excess_dev || !out_count_dev || !out_flags_dev || !out_velocity_dev ||
+        n_frames < 0 || n_bins < 1)
+        return fail(AA_ERR_ARG, "aa_onset_gates_device: bad argument");
+    if (n_bins > 4160)
+        return fail(AA_ERR_UNSUPPORTED, "aa_onset_gates_device: n_bins > 4160 is not built (got %d)", n_bins);
+    AA_HIP(aa::launch_onset_gates(mags_dev, flux_dev, energy_dev, global_floor_dev, state_dev, initialized,
+                                  n_frames, n_bins, out_flux_dev, out_ema_dev, out_excess_dev, out_count_dev,
+                                  out_flags_dev, out_velocity_dev, (hipStream_t)stream));
+    return AA_OK;
+}
+
 // ------------------------------------------------------------------- tuner front --
 int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
                           const float *global_floor_dev, float *state_dev, int32_t initialized,

@@ -123,6 +123,10 @@ hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float 
                             hipStream_t stream);
 hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
                              int64_t n_frames, int n_bins, hipStream_t stream);
+hipError_t launch_onset_gates(const float *mags, const float *flux, const float *energy,
+                              const float *global_floor, float *state, int initialized, int64_t n_frames,
+                              int n_bins, float *out_flux, float *out_ema, float *out_excess,
+                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream);
 hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
                               int initialized, float *eff, int64_t n_frames, int n_bins,
                               hipStream_t stream);

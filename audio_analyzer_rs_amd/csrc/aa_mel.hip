@@ -9,6 +9,7 @@
 //   DCT-II  orthonormal, [n_mels -> n_mfcc]: the same GEMM kernel with the DCT matrix as B.
 // Also the stereo -> mono average of the capture callback (src/audio_io/mod.rs:784-794).
 #include "aa_internal.hpp"
+#include <type_traits>
 
 namespace aa {
 namespace {
@@ -160,6 +161,188 @@ __global__ __launch_bounds__(256) void onset_flux_kernel(const float *__restrict
     }
 }
 
+// Rest of the onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
+// 531-535; "next" row f-2): per-bin rise-once burst floor, silence gate, energy EMA, FluxTracker,
+// combined trigger, energy_rising, velocity and the frames_since_onset gate (offline semantics:
+// transport calibrated, no metronome tick nearby).  A recurrence over frames: ONE wave walks the
+// frames of a stream in order, lanes = bins (floors in LDS), the burst count is a ballot + popcount
+// and the largest excess a wave max (both order-independent), the scalar recurrences run
+// redundantly in every lane in the reference's operation order -> bit-identical to the CPU
+// restatement.  Magnitude rows are prefetched a block of frames ahead into registers and handed
+// over through LDS; per-frame scalars in and out travel as one lane per frame of the block.
+constexpr int kGatePrefetchRegs = 65;               // a block of frames holds <= 64 * 65 floats
+// wave-wide max without LDS traffic: DPP row rotations inside the 16-lane rows, then
+// v_permlane16/32_swap across rows (a single wave has nothing to hide a ds_bpermute behind)
+__device__ __forceinline__ float gate_wave_max(float v)
+{
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value,
+                                                          0xF, 0xF, false));
+    };
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x121>()));   // row_ror:1
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x122>()));   // row_ror:2
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x124>()));   // row_ror:4
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x128>()));   // row_ror:8
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+// BPL = bins per lane (ceil(n_bins / 64)): the floors live in registers, bin k = 64 j + lane.
+template <int BPL>
+__global__ __launch_bounds__(64) void onset_gates_kernel(
+    const float *__restrict__ mags, const float *__restrict__ flux, const float *__restrict__ energy,
+    const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
+    int n_bins, int frames_per_block, float *__restrict__ out_flux, float *__restrict__ out_ema,
+    float *__restrict__ out_excess, int32_t *__restrict__ out_count, uint8_t *__restrict__ out_flags,
+    float *__restrict__ out_velocity)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float gate_lds[];
+    const int lane = threadIdx.x;
+    float *blk = gate_lds;                           // frames_per_block rows of magnitudes (+ one pad row)
+    const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
+    const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
+    const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
+    float fl[BPL];
+    bool valid[BPL];
+#pragma unroll
+    for (int j = 0; j < BPL; ++j) {
+        valid[j] = 64 * j + lane < n_bins;
+        fl[j] = valid[j] ? state[64 * j + lane] : 1.0f;
+    }
+    float ema = 0.0f, thr = 0.0f;
+    int since = 4;
+    bool init = initialized != 0;
+    if (init) {
+        ema = state[n_bins];
+        thr = state[n_bins + 1];
+        since = __float_as_int(state[n_bins + 2]);
+    }
+    const int block_floats = frames_per_block * n_bins;
+    const int64_t n_blocks = (n_frames + frames_per_block - 1) / frames_per_block;
+    float nxt[kGatePrefetchRegs];
+    auto fetch = [&](int64_t b) {
+        const int64_t base = b * block_floats;
+        const int64_t left = n_frames * n_bins - base;
+#pragma unroll
+        for (int i = 0; i < kGatePrefetchRegs; ++i) {
+            const int idx = i * 64 + lane;
+            nxt[i] = (idx < block_floats && idx < left) ? mags[base + idx] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kGatePrefetchRegs; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < block_floats)
+                blk[idx] = nxt[i];
+        }
+        __syncthreads();
+        if (b + 1 < n_blocks)
+            fetch(b + 1);                            // in flight while this block is walked
+        const int64_t t0 = b * frames_per_block;
+        const int nfb = (int)((n_frames - t0) < frames_per_block ? (n_frames - t0) : frames_per_block);
+        const bool mine = lane < nfb;
+        const float in_flux = mine ? flux[t0 + lane] : 0.0f, in_energy = mine ? energy[t0 + lane] : 0.0f;
+        const float in_gf = mine ? global_floor[t0 + lane] : 0.0f;
+        float o_flux = 0.0f, o_ema = 0.0f, o_exc = 0.0f, o_vel = 0.0f;
+        int o_count = 0, o_flags = 0;
+        // this frame's magnitudes; the next frame's are read from LDS one iteration ahead
+        float mcur[BPL], mnext[BPL];
+#pragma unroll
+        for (int j = 0; j < BPL; ++j)
+            mcur[j] = valid[j] ? blk[64 * j + lane] : 0.0f;
+        for (int i = 0; i < nfb; ++i) {
+            const float *mn = blk + (i + 1) * n_bins;            // row nfb is the pad row
+#pragma unroll
+            for (int j = 0; j < BPL; ++j)
+                mnext[j] = valid[j] ? mn[64 * j + lane] : 0.0f;
+            float current_flux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in_flux), i));
+            const float frame_energy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in_energy), i));
+            const float gf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in_gf), i));
+            const float floor_eps = fmaxf(gf, 0.01f);
+            if (!init) {
+#pragma unroll
+                for (int j = 0; j < BPL; ++j)
+                    fl[j] = fmaxf(mcur[j], gf);
+                init = true;
+            }
+            float mx = 0.0f;
+            int count = 0;
+#pragma unroll
+            for (int j = 0; j < BPL; ++j) {
+                const float mag = mcur[j], f = fl[j];
+                const float r = mag / fmaxf(f, floor_eps);
+                const bool burst = valid[j] && r > BIN_BURST_RATIO;
+                float nf;
+                if (burst)
+                    nf = mag * FLOOR_OVERCOMPENSATE;
+                else if (mag > f)
+                    nf = f + FLOOR_RISE * (mag - f);
+                else
+                    nf = f + FLOOR_DECAY * (mag - f);
+                fl[j] = nf;
+                count += __popcll(__ballot(burst));
+                if (valid[j] && r > mx)
+                    mx = r;
+            }
+            mx = gate_wave_max(mx);
+            if (count < 2)
+                current_flux = 0.0f;
+            const float ema_memory = frame_energy > ema ? ENERGY_EMA_RISE : ENERGY_EMA_DECAY;
+            ema = ema * ema_memory + frame_energy * (1.0f - ema_memory);
+            const float memory = current_flux > thr ? rise_memory : decay_memory;
+            const bool is_onset = current_flux > thr;
+            thr = thr * memory + current_flux * (1.0f - memory);
+            if (thr < 0.9f)
+                thr = 0.9f;
+            const bool flux_onset = is_onset && current_flux > thr * multiplier;
+            const bool burst_onset = mx > 3.0f && count >= 3;
+            const bool detected = flux_onset && burst_onset;
+            const bool rising = frame_energy > ema * 1.5f;
+            const bool fired = detected && rising && since >= 3;
+            float vel = fmaxf(current_flux, mx * 5.0f) / 50.0f;
+            vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
+            if (fired || (detected && since < 3))
+                since = 0;
+            else if (since < 0x7fffffff)
+                since += 1;
+            if (lane == i) {
+                o_flux = current_flux;
+                o_ema = ema;
+                o_exc = mx;
+                o_vel = vel;
+                o_count = count;
+                o_flags = (int)flux_onset | ((int)burst_onset << 1) | ((int)detected << 2) | ((int)rising << 3) |
+                          ((int)fired << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < BPL; ++j)
+                mcur[j] = mnext[j];
+        }
+        if (mine) {
+            out_flux[t0 + lane] = o_flux;
+            out_ema[t0 + lane] = o_ema;
+            out_excess[t0 + lane] = o_exc;
+            out_count[t0 + lane] = o_count;
+            out_flags[t0 + lane] = (uint8_t)o_flags;
+            out_velocity[t0 + lane] = o_vel;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BPL; ++j)
+        if (valid[j])
+            state[64 * j + lane] = fl[j];
+    if (lane == 0) {
+        state[n_bins] = ema;
+        state[n_bins + 1] = thr;
+        state[n_bins + 2] = __int_as_float(since);
+    }
+}
+
 // Tuner front end (src/audio_io/stft.rs:326-367), first stage of "next" row f-1: the variance-
 // aware per-bin noise floor.  It is a recurrence over frames, independent per bin: one lane per
 // bin walks the frames in order with exactly the reference's operation order (contraction off,
@@ -252,6 +435,36 @@ hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux,
         blocks = 8192;
     hipLaunchKernelGGL(onset_flux_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mags, prev0, flux,
                        energy, n_frames, n_bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_onset_gates(const float *mags, const float *flux, const float *energy,
+                              const float *global_floor, float *state, int initialized, int64_t n_frames,
+                              int n_bins, float *out_flux, float *out_ema, float *out_excess,
+                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    if (n_bins < 1 || n_bins > 64 * kGatePrefetchRegs)
+        return hipErrorInvalidValue;
+    int fpb = 64 * kGatePrefetchRegs / n_bins;       // frames per prefetched block, one lane per frame
+    if (fpb > 64)
+        fpb = 64;
+    const size_t lds = sizeof(float) * (size_t)((fpb + 1) * n_bins);   // + the pad row read one frame ahead
+    const int bpl = (n_bins + 63) / 64;
+#define AA_GATES(B)                                                                                      \
+    hipLaunchKernelGGL(onset_gates_kernel<B>, dim3(1), dim3(64), lds, stream, mags, flux, energy,        \
+                       global_floor, state, initialized, n_frames, n_bins, fpb, out_flux, out_ema,       \
+                       out_excess, out_count, out_flags, out_velocity)
+    if (bpl <= 3)
+        AA_GATES(3);        // 129 bins: the onset geometry (onset.rs:122-125)
+    else if (bpl <= 9)
+        AA_GATES(9);
+    else if (bpl <= 17)
+        AA_GATES(17);
+    else
+        AA_GATES(65);
+#undef AA_GATES
     return hipGetLastError();
 }
 

@@ -153,6 +153,41 @@ def onset_flux(mags, prev_row=None, stream=None):
     return flux, energy
 
 
+ONSET_FLAG_FLUX, ONSET_FLAG_BURST, ONSET_FLAG_DETECTED, ONSET_FLAG_ENERGY_RISING, ONSET_FLAG_FIRED = 1, 2, 4, 8, 16
+
+
+def onset_gates(mags, flux, energy, global_floor, state=None, stream=None):
+    """The onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
+    531-535): burst floor, silence gate, energy EMA, FluxTracker, combined trigger, velocity,
+    frames_since_onset gate (calibrated transport, no metronome tick).  All arguments are CUDA
+    tensors: mags float32 [frames, bins]; flux, energy, global_floor float32 [frames].  state:
+    None for a fresh detector, or the [bins + 3] tensor returned by a previous call.
+    Returns (dict of per-frame tensors, state)."""
+    import torch
+
+    lib = _lib.load()
+    nf, nb = mags.shape
+    initialized = state is not None
+    if state is None:
+        state = torch.zeros(nb + 3, dtype=torch.float32, device=mags.device)
+    out = {
+        "flux": torch.empty(nf, dtype=torch.float32, device=mags.device),
+        "energy_ema": torch.empty(nf, dtype=torch.float32, device=mags.device),
+        "max_excess": torch.empty(nf, dtype=torch.float32, device=mags.device),
+        "burst_count": torch.empty(nf, dtype=torch.int32, device=mags.device),
+        "flags": torch.empty(nf, dtype=torch.uint8, device=mags.device),
+        "velocity": torch.empty(nf, dtype=torch.float32, device=mags.device),
+    }
+    st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
+    if nf:
+        _lib.check(lib.aa_onset_gates_device(
+            mags.data_ptr(), nf, nb, flux.data_ptr(), energy.data_ptr(), global_floor.data_ptr(),
+            state.data_ptr(), 1 if initialized else 0, out["flux"].data_ptr(), out["energy_ema"].data_ptr(),
+            out["max_excess"].data_ptr(), out["burst_count"].data_ptr(), out["flags"].data_ptr(),
+            out["velocity"].data_ptr(), st))
+    return out, state
+
+
 def tuner_floor(mags, global_floor, state=None, stream=None):
     """Per-bin adaptive noise floor of the tuner (src/audio_io/stft.rs:326-367) for a CUDA float32
     magnitude spectrogram [frames, bins].  global_floor: CUDA float32 [frames]

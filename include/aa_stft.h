@@ -180,6 +180,32 @@ int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t ch
 int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
                          const float *prev_row_dev, float *flux_dev, float *energy_dev, void *stream);
 
+/* ---- onset detector: burst floor, gates and trackers (src/analysis/onset.rs:298-371, 531-535) ---- */
+/* The per-frame logic that follows the flux in the reference's onset thread ("next" row f-2):
+ *   per bin   r = mag / max(floor, max(global_floor, 0.01));  r > 2.5: burst, floor = 1.3 mag;
+ *             else floor += (mag > floor ? 0.1 : 0.04) * (mag - floor)            (onset.rs:311-332)
+ *   frame     burst_count, max_excess = max r; flux = 0 when burst_count < 2       (:337-339)
+ *             energy EMA (0.84 rising / 0.95 falling)                              (:345-350)
+ *             FluxTracker(1.5, 0.84, 0.89)::update -> flux_onset                   (:66-83, :158)
+ *             bin_burst_onset = max_excess > 3 && burst_count >= 3; onset_detected (:355-357)
+ *             energy_rising = energy > 1.5 ema (:373); velocity (:389-390)
+ *             frames_since_onset gate (:402, :531-535)
+ * with the transport-dependent parts fixed to "calibrated, no metronome tick nearby":
+ * onset_fired = onset_detected && energy_rising && frames_since_onset >= 3.
+ * Inputs: magnitude rows [n_frames x n_bins], flux / frame energy per frame (aa_onset_flux_device),
+ * global_floor per frame (= 10^(noise_floor_db/20) * n_bins / 2, onset.rs:299-300).
+ * state_dev: n_bins + 3 floats {floors, energy_ema, tracker threshold, frames_since_onset (int
+ * bits)}, updated in place; `initialized` = 0 starts a fresh detector.
+ * Outputs per frame: gated flux, energy EMA, max_excess, burst count, velocity and
+ * flags = flux_onset | bin_burst_onset << 1 | onset_detected << 2 | energy_rising << 3 |
+ * onset_fired << 4.  One wave walks the frames in order in the reference's operation order:
+ * every output is bit-identical to the sequential f32 evaluation on the same inputs. */
+int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bins, const float *flux_dev,
+                          const float *energy_dev, const float *global_floor_dev, float *state_dev,
+                          int32_t initialized, float *out_flux_dev, float *out_ema_dev,
+                          float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                          float *out_velocity_dev, void *stream);
+
 /* ---- tuner front end: per-bin adaptive noise floor (src/audio_io/stft.rs:326-367) ---- */
 /* First stage after the tuner STFT.  For every bin a first-order
  * recurrence over frames with the reference's constants (stft.rs:219-224):

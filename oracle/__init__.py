@@ -15,6 +15,7 @@ from .capi import (  # noqa: F401
     hann_window,
     num_frames,
     onset_flux,
+    onset_gates,
     rfft_forward,
     rfft_inverse,
     stft,

@@ -60,6 +60,10 @@ class Oracle:
         lib.aao_stream_push.restype = ctypes.c_int64
         lib.aao_onset_flux.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p]
         lib.aao_onset_flux.restype = None
+        lib.aao_onset_gates.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
+                                        ctypes.POINTER(ctypes.c_int), _f32p, _f32p, _f32p,
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8), _f32p]
+        lib.aao_onset_gates.restype = None
         lib.aao_tuner_floor.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_int), _f32p]
         lib.aao_tuner_floor.restype = None
@@ -204,3 +208,24 @@ def tuner_floor(mags, global_floor, state=None, initialized=False):
     eff = np.empty((nf, nb), dtype=np.float32)
     Oracle.get().lib.aao_tuner_floor(_ptr(mags), nf, nb, _ptr(gf), _ptr(st), ctypes.byref(init), _ptr(eff))
     return eff, st, bool(init.value)
+
+
+def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False):
+    """Onset detector logic after the flux (src/analysis/onset.rs:298-371, 531-535), sequential f32.
+    Returns (dict of per-frame arrays, state [bins + 3], initialized)."""
+    mags = np.ascontiguousarray(mags, dtype=np.float32)
+    nf, nb = mags.shape
+    flux = np.ascontiguousarray(flux, dtype=np.float32)
+    energy = np.ascontiguousarray(energy, dtype=np.float32)
+    gf = np.ascontiguousarray(np.broadcast_to(np.asarray(global_floor, dtype=np.float32), (nf,)))
+    st = np.zeros(nb + 3, dtype=np.float32) if state is None else np.array(state, dtype=np.float32)
+    init = ctypes.c_int(1 if initialized else 0)
+    out = {"flux": np.empty(nf, np.float32), "energy_ema": np.empty(nf, np.float32),
+           "max_excess": np.empty(nf, np.float32), "burst_count": np.empty(nf, np.int32),
+           "flags": np.empty(nf, np.uint8), "velocity": np.empty(nf, np.float32)}
+    Oracle.get().lib.aao_onset_gates(
+        _ptr(mags), nf, nb, _ptr(flux), _ptr(energy), _ptr(gf), _ptr(st), ctypes.byref(init), _ptr(out["flux"]),
+        _ptr(out["energy_ema"]), _ptr(out["max_excess"]),
+        out["burst_count"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        out["flags"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _ptr(out["velocity"]))
+    return out, st, bool(init.value)

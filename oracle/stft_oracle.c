@@ -437,6 +437,96 @@ void aao_onset_flux(const float *mags, int64_t n_frames, int n_bins, const float
     }
 }
 
+/* Rest of the onset detector's per-frame logic (src/analysis/onset.rs:298-371, 531-535) after
+ * the flux: per-bin "rise-once, suppress" burst floor (:311-332), silence gate (:337-339),
+ * energy EMA (:345-350), FluxTracker::update (:66-83, constructed :158 with (1.5, 0.84, 0.89)),
+ * combined trigger (:355-357), energy_rising (:373), velocity (:389-390) and the
+ * frames_since_onset gate (:402, 531-535).  Offline semantics: transport calibrated and no
+ * metronome tick nearby, i.e. onset_fired = onset_detected && energy_rising &&
+ * frames_since_onset >= 3.
+ * state: n_bins floors, then energy_ema, tracker threshold, frames_since_onset (int bits).
+ * flags: bit0 flux_onset, bit1 bin_burst_onset, bit2 onset_detected, bit3 energy_rising,
+ * bit4 onset_fired.  Plain f32 in the reference's operation order (-ffp-contract=off). */
+void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const float *flux,
+                     const float *energy, const float *global_floor, float *state, int *initialized,
+                     float *out_flux, float *out_ema, float *out_excess, int32_t *out_count,
+                     uint8_t *out_flags, float *out_velocity)
+{
+    const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
+    const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
+    const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
+    float *fl = state;
+    float ema, thr;
+    int32_t since;
+    if (*initialized) {
+        ema = state[n_bins];
+        thr = state[n_bins + 1];
+        memcpy(&since, &state[n_bins + 2], sizeof since);
+    } else {
+        ema = 0.0f;
+        thr = 0.0f;
+        since = 4;
+    }
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const float *m = mags + t * (int64_t)n_bins;
+        float current_flux = flux[t];
+        const float frame_energy = energy[t], gf = global_floor[t];
+        const float floor_eps = fmaxf(gf, 0.01f);
+        if (!*initialized) {
+            for (int k = 0; k < n_bins; ++k)
+                fl[k] = fmaxf(m[k], gf);
+            *initialized = 1;
+        }
+        float max_bin_excess = 0.0f;
+        int32_t bin_burst_count = 0;
+        for (int k = 0; k < n_bins; ++k) {
+            const float mag = m[k];
+            const float floor_k = fmaxf(fl[k], floor_eps);
+            const float r = mag / floor_k;
+            if (r > BIN_BURST_RATIO) {
+                bin_burst_count += 1;
+                fl[k] = mag * FLOOR_OVERCOMPENSATE;
+            } else if (mag > fl[k]) {
+                fl[k] += FLOOR_RISE * (mag - fl[k]);
+            } else {
+                fl[k] += FLOOR_DECAY * (mag - fl[k]);
+            }
+            if (r > max_bin_excess)
+                max_bin_excess = r;
+        }
+        if (bin_burst_count < 2)
+            current_flux = 0.0f;
+        const float ema_memory = frame_energy > ema ? ENERGY_EMA_RISE : ENERGY_EMA_DECAY;
+        ema = ema * ema_memory + frame_energy * (1.0f - ema_memory);
+        const float memory = current_flux > thr ? rise_memory : decay_memory;
+        const int is_onset = current_flux > thr;
+        thr = thr * memory + current_flux * (1.0f - memory);
+        if (thr < 0.9f)
+            thr = 0.9f;
+        const int flux_onset = is_onset && current_flux > thr * multiplier;
+        const int bin_burst_onset = max_bin_excess > 3.0f && bin_burst_count >= 3;
+        const int onset_detected = flux_onset && bin_burst_onset;
+        const int energy_rising = frame_energy > ema * 1.5f;
+        const int fired = onset_detected && energy_rising && since >= 3;
+        float vel = fmaxf(current_flux, max_bin_excess * 5.0f) / 50.0f;
+        vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
+        if (fired || (onset_detected && since < 3))
+            since = 0;
+        else if (since < INT32_MAX)
+            since += 1;
+        out_flux[t] = current_flux;
+        out_ema[t] = ema;
+        out_excess[t] = max_bin_excess;
+        out_count[t] = bin_burst_count;
+        out_flags[t] = (uint8_t)(flux_onset | (bin_burst_onset << 1) | (onset_detected << 2) |
+                                 (energy_rising << 3) | (fired << 4));
+        out_velocity[t] = vel;
+    }
+    state[n_bins] = ema;
+    state[n_bins + 1] = thr;
+    memcpy(&state[n_bins + 2], &since, sizeof since);
+}
+
 /* -------------------------------------- tuner front: per-bin noise floor -- */
 
 /* Variance-aware per-bin noise floor of STFT::detect_pitches

@@ -363,6 +363,39 @@ def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
     assert torch_mod.equal(f2, flux[2500:]) and torch_mod.equal(e2, energy[2500:])
 
 
+@pytest.mark.parametrize("n,hop", [(256, 64), (1024, 256)])
+def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
+    """Rest of "next" row f-2: burst floor, silence gate, energy EMA, FluxTracker, trigger and
+    frame gate of the onset detector (onset.rs:298-371, 531-535).  Integer / boolean / recurrence
+    work: every output bit-identical to the sequential restatement on the same inputs (the GPU
+    magnitudes and flux), also when the stream is fed in pieces."""
+    from test_oracle import _burst_signal
+
+    x = _burst_signal(seconds=6.0, seed=11)
+    xd = torch_mod.from_numpy(x).cuda()
+    mags = aa.Stft(n, hop, output="mag")(xd)
+    nb = mags.shape[1]
+    flux, energy = aa.onset_flux(mags)
+    nf = mags.shape[0]
+    gf_db = -60.0 + 6.0 * np.sin(np.arange(nf) / 500.0)
+    gf = (10.0 ** (gf_db / 20.0) * nb / 2.0).astype(np.float32)
+    gfd = torch_mod.from_numpy(gf).cuda()
+    out, state = aa.onset_gates(mags, flux, energy, gfd)
+    ref, ref_state, _ = oracle_mod.onset_gates(mags.cpu().numpy(), flux.cpu().numpy(), energy.cpu().numpy(), gf)
+    for key in ref:
+        assert np.array_equal(out[key].cpu().numpy(), ref[key]), key
+    assert np.array_equal(state.cpu().numpy().view(np.uint32), ref_state.view(np.uint32))
+    assert int((out["flags"] & aa.stft.ONSET_FLAG_FIRED).bool().sum()) >= 20
+    cut = 1234
+    o1, s1 = aa.onset_gates(mags[:cut].contiguous(), flux[:cut].contiguous(), energy[:cut].contiguous(),
+                            gfd[:cut].contiguous())
+    o2, s2 = aa.onset_gates(mags[cut:].contiguous(), flux[cut:].contiguous(), energy[cut:].contiguous(),
+                            gfd[cut:].contiguous(), state=s1)
+    for key in out:
+        assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), out[key]), key
+    assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32))
+
+
 def test_tuner_noise_floor_bit_exact(aa, oracle_mod, torch_mod):
     """First stage of "next" row f-1: the tuner's per-bin adaptive noise floor
     (stft.rs:326-367) on the tuner geometry — a recurrence, evaluated in the reference's

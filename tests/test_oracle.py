@@ -119,6 +119,42 @@ def test_onset_flux_restatement(oracle_mod):
     assert f2[0] == flux[1] and e2[0] == energy[1]
 
 
+def _burst_signal(seconds=4.0, sr=48000, seed=5):
+    """Quiet noise with decaying tone bursts every 250 ms (what an onset detector listens for)."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * sr)
+    x = (2e-3 * rng.standard_normal(n)).astype(np.float32)
+    t = np.arange(int(0.12 * sr)) / sr
+    for k, start in enumerate(range(sr // 5, n - len(t), sr // 4)):
+        f = 220.0 * (1.0 + 0.37 * k)
+        x[start:start + len(t)] += (0.5 * np.exp(-t / 0.03) * np.sin(2 * np.pi * f * t)).astype(np.float32)
+    return x
+
+
+def test_onset_gates_restatement(oracle_mod):
+    # onset.rs:298-371, 531-535 on the onset geometry: bursts fire, silence does not, state carries
+    x = _burst_signal()
+    mags = oracle_mod.stft(x, 256, 64, kind="mag")
+    flux, energy = oracle_mod.onset_flux(mags)
+    gf = np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0)
+    out, st, init = oracle_mod.onset_gates(mags, flux, energy, gf)
+    fired = np.nonzero(out["flags"] & 16)[0]
+    starts = np.arange(48000 // 5, len(x) - int(0.12 * 48000), 48000 // 4)
+    assert init and len(fired) == len(starts)
+    # every burst start is reported within one window of its frame
+    assert np.all(np.abs(fired * 64 - (starts - 128)) <= 256)
+    assert out["burst_count"].dtype == np.int32 and out["burst_count"].max() >= 3
+    assert np.all(out["flux"][out["burst_count"] < 2] == 0.0)          # silence gate
+    assert np.all((out["velocity"] >= 0.0) & (out["velocity"] <= 1.0))
+    # two pieces with the carried state == one piece
+    cut = 1111
+    o1, s1, i1 = oracle_mod.onset_gates(mags[:cut], flux[:cut], energy[:cut], gf)
+    o2, s2, _ = oracle_mod.onset_gates(mags[cut:], flux[cut:], energy[cut:], gf, state=s1, initialized=i1)
+    for key in out:
+        assert np.array_equal(np.concatenate([o1[key], o2[key]]), out[key]), key
+    assert np.array_equal(s2, st)
+
+
 def test_tuner_floor_restatement(oracle_mod):
     # stft.rs:326-367 — first frame initialises, a steady loud bin freezes, quiet bins release
     nb = 4
