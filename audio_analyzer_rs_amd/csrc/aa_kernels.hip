@@ -119,25 +119,40 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)      // a * w
         : "v"(a), "v"(w), "v"(t));
     return r;
 }
-// 8-point DFT over the register index on packed values (same radix-2 DIF flow as dft8).
+// c + (-i) h g  and  c + (+i) h g  for a packed constant h = (s, s): the rotation is the half swap
+// of g (op_sel) and a sign on one half of h (neg), the scale rides in the FMA.
+__device__ __forceinline__ v2f pk_fma_mi(v2f g, v2f h, v2f c)   // (c.x + h g.y, c.y - h g.x)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(g), "v"(h), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_pi(v2f g, v2f h, v2f c)   // (c.x - h g.y, c.y + h g.x)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(g), "v"(h), "v"(c));
+    return r;
+}
+// 8-point DFT over the register index on packed values (same radix-2 DIF flow as dft8).  The two
+// multiplications by sqrt(1/2) (W8^1, W8^3) are folded into the FMAs of the last stage:
+// with p = (1 - i) b1 and q = (1 + i) b3:  W8^1 b1 = h p,  W8^3 b3 = -h q.
 __device__ __forceinline__ void pk_dft8(v2f (&v)[8])
 {
     const v2f hp = {0.70710678118654752440f, 0.70710678118654752440f};
-    const v2f hn = {-0.70710678118654752440f, -0.70710678118654752440f};
     v2f a0 = v[0] + v[4], b0 = v[0] - v[4];
     v2f a1 = v[1] + v[5], b1 = v[1] - v[5];
     v2f a2 = v[2] + v[6], b2 = v[2] - v[6];
     v2f a3 = v[3] + v[7], b3 = v[3] - v[7];
-    b1 = pk_add_mi(b1, b1) * hp;                     // * W8^1 = (x+y, y-x) h
-    b3 = pk_add_pi(b3, b3) * hn;                     // * W8^3 = (y-x, -x-y) h
+    const v2f p = pk_add_mi(b1, b1);                 // (x + y, y - x)
+    const v2f q = pk_add_pi(b3, b3);                 // (x - y, x + y)
+    const v2f e = p - q, g = p + q;                  // d1 = h e, w = h g
     v2f c0 = a0 + a2, c2 = a0 - a2;
     v2f c1 = a1 + a3, u = a1 - a3;                   // c3 = -i u
     v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);   // b0 +- (-i b2)
-    v2f d1 = b1 + b3, w = b1 - b3;                   // d3 = -i w
     v[0] = c0 + c1; v[4] = c0 - c1;
     v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
-    v[1] = d0 + d1; v[5] = d0 - d1;
-    v[3] = pk_add_mi(d2, w); v[7] = pk_add_pi(d2, w);
+    v[1] = d0 + e * hp; v[5] = d0 - e * hp;
+    v[3] = pk_fma_mi(g, hp, d2); v[7] = pk_fma_pi(g, hp, d2);
 }
 
 // ---- cross-lane register transposes -----------------------------------------
@@ -1110,7 +1125,14 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
 // Table rows ([50][64]): 0..15 0.5*w[2(16j+q)+c] (row 2j+c), 16..29 W_128^(q k1) k1=1..7,
 // 30..35 DIF stage twiddles (d = 8, 4, 2), 36..39 sigma per stage, 40..49 -i W_256^k of the
 // lane's five pairs (k = (lane + 64 i) % 65).
-constexpr int kW256StripStride = 130;   // complex per frame in the strip (129 + 1: 16-B aligned rows)
+// Strip layout (complex units): Z[k] of frame f at f * kW256StripStride + (k >> 3) * kW256StripBlock
+// + (k & 7).  A lane writes its 8 consecutive Z as four ds_write_b128, which the LDS serves 16
+// lanes (one frame) at a time: with the blocks packed (stride 8 complex = 16 floats) the 16 lanes
+// hit 16 banks four deep (measured: 70 % of the kernel's LDS cycles were bank conflicts); padding
+// a block to 10 complex (20 floats = 4 x odd) spreads them over all 64 banks.
+constexpr int kW256StripBlock = 10;
+constexpr int kW256StripStride = 162;   // 16 blocks + Z[128], even (16-byte aligned strips)
+__device__ __forceinline__ int w256_strip_index(int k) { return (k >> 3) * kW256StripBlock + (k & 7); }
 
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ v2f dpp_pair(v2f old, v2f src)
@@ -1132,7 +1154,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
     const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
     const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
     const int max_span = (frames_per_wg - 1) * hop + 256;
-    float *scrf = smem + 2 * max_span + wave * kWave1024ScratchDwords;
+    float *scrf = smem + 2 * max_span + wave * kWave256ScratchDwords;
     v2f *scr = reinterpret_cast<v2f *>(scrf);
     constexpr int NB = 129;
     constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
@@ -1180,13 +1202,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
         const int p = lane + 64 * i;
         const int fr = p / 65, k = p - 65 * fr;
         pfr[i] = p < 260 ? fr : 4;                     // 4 = no such pair
-        pa[i] = (fr & 3) * kW256StripStride + k;
-        pb[i] = (fr & 3) * kW256StripStride + 128 - k;
+        pa[i] = (fr & 3) * kW256StripStride + w256_strip_index(k);
+        pb[i] = (fr & 3) * kW256StripStride + w256_strip_index(128 - k);
         rlo[i] = (fr & 3) * NB + k;
         rhi[i] = (fr & 3) * NB + 128 - k;
     }
     const int br = ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3);
-    v4f *strip_wr = reinterpret_cast<v4f *>(scr + fq * kW256StripStride + 8 * br);
+    v4f *strip_wr = reinterpret_cast<v4f *>(scr + fq * kW256StripStride + kW256StripBlock * br);
     const unsigned smem_addr = lds_addr(smem);
 
     for (int c = c0; c < c1; ++c) {
@@ -1260,7 +1282,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
             for (int i = 0; i < 4; ++i)
                 strip_wr[i] = v4f{v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y};
             if (q == 0)
-                scr[fq * kW256StripStride + 128] = v[0];
+                scr[fq * kW256StripStride + w256_strip_index(128)] = v[0];
             __builtin_amdgcn_wave_barrier();
             v2f za[5], zb[5];
 #pragma unroll
