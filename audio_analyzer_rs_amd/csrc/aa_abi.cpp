@@ -369,7 +369,8 @@ void build_wave256_table(const float *window, std::vector<float> *tab)
     tab->assign((size_t)aa::kWave256Rows * 64, 0.0f);
     float *T = tab->data();
     for (int lane = 0; lane < 64; ++lane) {
-        const int q = lane & 15;
+        // lane map before the exchange: lane = 8 q' + 2 frame + b, element column q = 8 b + q'
+        const int b = lane & 1, qp = lane >> 3, q = 8 * b + qp;
         for (int j = 0; j < 8; ++j)
             for (int c = 0; c < 2; ++c)
                 T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (16 * j + q) + c];
@@ -378,17 +379,11 @@ void build_wave256_table(const float *window, std::vector<float> *tab)
             T[(16 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
             T[(17 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
         }
-        const int dist[4] = {8, 4, 2, 1};
-        for (int s = 0; s < 4; ++s) {
-            const int d = dist[s];
-            const bool upper = (q & d) != 0;
-            T[(36 + s) * 64 + lane] = upper ? -1.0f : 1.0f;
-            if (s < 3) {
-                double a = upper ? -2.0 * kPi * (double)(q % d) / (2.0 * d) : 0.0;
-                T[(30 + 2 * s) * 64 + lane] = (float)std::cos(a);
-                T[(31 + 2 * s) * 64 + lane] = (float)std::sin(a);
-            }
-        }
+        // stage 0 (pair q', q' + 8): the odd half (b = 1) takes x[q'] - x[q' + 8], times W_16^(q')
+        T[36 * 64 + lane] = b ? -1.0f : 1.0f;
+        const double a0 = b ? -2.0 * kPi * (double)qp / 16.0 : 0.0;
+        T[30 * 64 + lane] = (float)std::cos(a0);
+        T[31 * 64 + lane] = (float)std::sin(a0);
         for (int i = 0; i < 5; ++i) {
             const int kk = (lane + 64 * i) % 65;
             double th = 2.0 * kPi * (double)kk / 256.0;

@@ -87,7 +87,7 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
 
 // ---- wave-per-4-frames 256-point kernel (onset geometry) ---------------------------
 constexpr int kWave256Rows = 50;
-constexpr int kWave256ScratchDwords = 1312;         // per wave: four padded strips of 162 complex
+constexpr int kWave256ScratchDwords = 1152;         // per wave: exchange (1056) / four strips of 144 complex
 inline int64_t wave256_lds_dwords(int frames_per_wg, int hop)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 256;

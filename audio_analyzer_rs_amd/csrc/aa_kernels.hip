@@ -1110,29 +1110,27 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
 
 // ----------------------------------------------------- wave-per-4-frames, n_fft = 256 --
 // The onset geometry of the reference (window 256, hop 64: src/analysis/onset.rs:122-123).
-// 128 complex points per frame: 16 lanes per frame (one DPP row), 8 points per lane, so one
-// wave transforms FOUR consecutive frames at once:
-//   pass A   radix-8 over j in registers (lane q reads m = 16 j + q), x W_128^(q k1)
-//   16-point radix-2 DIF across the 16 lanes of a row, for all 8 registers at once: partner
-//            via DPP (row_ror:8, row_shl/shr:4 with bank masks, quad_perm), butterfly as one
-//            packed fma  y = sigma x + partner  (sigma = -1 on the upper lane), stage twiddle
-//   -> lane q holds Z[k1 + 8 bitrev4(q)]
-//   split    Z of the 4 frames goes to a wave-private LDS strip (4 x ds_write_b128 per lane);
-//            260 (k, 128-k) pairs are spread over the 64 lanes (5 per lane), each pair yields
-//            X[k] and X[128-k]; magnitudes land in a dense 4-row LDS image
+// 128 complex points per frame, 16 lanes per frame, 8 points per lane, FOUR frames per wave:
+//   z[m], m = 16 j + q:  lane holds q (0..15), register j (0..7)
+//   pass A   radix-8 over j in registers, x W_128^(q k1)                  -> Y'[q][k1]
+//   stage 0  one radix-2 DIF butterfly across the lane pair (q', q' + 8) by DPP quad_perm (the
+//            pair sits in adjacent lanes, see the lane map), x W_16^(q') on the odd half:
+//            Z[k1 + 8 (2 mu + b)] = sum_q' W_8^(q' mu) u_b[q'][k1]
+//   E        registers <-> lanes through the wave's LDS scratch, the 8 x 8 transposes of
+//            stft_wave1024_kernel's E1 (same addresses, conflict free): q' <-> k1
+//   pass C   radix-8 over q' in registers -> lane l (0..15 of its frame) holds Z[l + 16 mu]
+//   split    Z of the 4 frames goes to an LDS strip (8 x ds_write_b64 per lane); 260 (k, 128-k)
+//            pairs are spread over the 64 lanes (5 per lane), each pair yields X[k] and
+//            X[128-k]; magnitudes land in a dense 4-row LDS image
 //   store    4 rows x 129 floats = 129 float4: rows 4g..4g+3 start 16-byte aligned, so the
 //            image leaves as 3 nontemporal dwordx4 stores per FOUR frames.
+// Lane map before E: lane = 8 q' + 2 frame + b (q = 8 b + q'); after E: lane = 16 frame + l.
+// (First version: all four radix-2 stages of the 16-point transform as DPP butterflies - 55 % more
+// VALU instructions per sample than the 1024 kernel, which made this kernel VALU bound.)
 // Table rows ([50][64]): 0..15 0.5*w[2(16j+q)+c] (row 2j+c), 16..29 W_128^(q k1) k1=1..7,
-// 30..35 DIF stage twiddles (d = 8, 4, 2), 36..39 sigma per stage, 40..49 -i W_256^k of the
-// lane's five pairs (k = (lane + 64 i) % 65).
-// Strip layout (complex units): Z[k] of frame f at f * kW256StripStride + (k >> 3) * kW256StripBlock
-// + (k & 7).  A lane writes its 8 consecutive Z as four ds_write_b128, which the LDS serves 16
-// lanes (one frame) at a time: with the blocks packed (stride 8 complex = 16 floats) the 16 lanes
-// hit 16 banks four deep (measured: 70 % of the kernel's LDS cycles were bank conflicts); padding
-// a block to 10 complex (20 floats = 4 x odd) spreads them over all 64 banks.
-constexpr int kW256StripBlock = 10;
-constexpr int kW256StripStride = 162;   // 16 blocks + Z[128], even (16-byte aligned strips)
-__device__ __forceinline__ int w256_strip_index(int k) { return (k >> 3) * kW256StripBlock + (k & 7); }
+// 30..31 stage-0 twiddle, 36 stage-0 sign, 40..49 -i W_256^k of the lane's five pairs
+// (k = (lane + 64 i) % 65).
+constexpr int kW256StripStride = 144;   // complex per frame in the strip (>= 129; 2*144 = 32 mod 64)
 
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ v2f dpp_pair(v2f old, v2f src)
@@ -1149,7 +1147,9 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fq = lane >> 4, q = lane & 15;           // frame-in-group, lane-in-frame
+    // lane map before the exchange E (frame read, pass A, stage 0) and after it (split, store)
+    const int fqA = (lane >> 1) & 3, qA = 8 * (lane & 1) + (lane >> 3);
+    const int fqB = lane >> 4, lB = lane & 15;
 
     const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
     const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
@@ -1178,19 +1178,15 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
     if (c0 < c1)
         stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
 
-    v2f win[8], twA[8], wst[3], sig[4], tws[5];
+    v2f win[8], twA[8], wst0, sig0, tws[5];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
 #pragma unroll
     for (int k = 1; k < 8; ++k)
         twA[k] = v2f{tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]};
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        wst[s] = v2f{tab[(30 + 2 * s) * 64 + lane], tab[(31 + 2 * s) * 64 + lane]};
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        sig[s] = v2f{tab[(36 + s) * 64 + lane], tab[(36 + s) * 64 + lane]};
+    wst0 = v2f{tab[30 * 64 + lane], tab[31 * 64 + lane]};
+    sig0 = v2f{tab[36 * 64 + lane], tab[36 * 64 + lane]};
 #pragma unroll
     for (int i = 0; i < 5; ++i)
         tws[i] = v2f{tab[(40 + 2 * i) * 64 + lane], tab[(41 + 2 * i) * 64 + lane]};
@@ -1202,13 +1198,14 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
         const int p = lane + 64 * i;
         const int fr = p / 65, k = p - 65 * fr;
         pfr[i] = p < 260 ? fr : 4;                     // 4 = no such pair
-        pa[i] = (fr & 3) * kW256StripStride + w256_strip_index(k);
-        pb[i] = (fr & 3) * kW256StripStride + w256_strip_index(128 - k);
+        pa[i] = (fr & 3) * kW256StripStride + k;
+        pb[i] = (fr & 3) * kW256StripStride + 128 - k;
         rlo[i] = (fr & 3) * NB + k;
         rhi[i] = (fr & 3) * NB + 128 - k;
     }
-    const int br = ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3);
-    v4f *strip_wr = reinterpret_cast<v4f *>(scr + fq * kW256StripStride + kW256StripBlock * br);
+    v2f *e_wr = scr + 66 * (lane & 7) + (lane >> 3);                        // + 8 k1   (E, as E1 at 1024)
+    const v4f *e_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    v2f *strip_wr = scr + fqB * kW256StripStride + lB;                      // + 16 mu
     const unsigned smem_addr = lds_addr(smem);
 
     for (int c = c0; c < c1; ++c) {
@@ -1227,10 +1224,10 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
             const int nleft = frames_left - frames_per_wg;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
-        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * q);
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * qA);
 
         for (int g = wave; 4 * g < nf; g += 4) {
-            const int t = 4 * g + fq;                  // this lane's frame within the chunk
+            const int t = 4 * g + fqA;                 // this lane's frame within the chunk
             const int nvalid = nf - 4 * g < 4 ? nf - 4 * g : 4;
             // a lane of a frame past the end reads the last valid frame instead (stays in the
             // staged span); its results are never stored
@@ -1249,40 +1246,24 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
             for (int k = 1; k < 8; ++k)
                 v[k] = pk_cmul(v[k], twA[k]);
 
-            // ---- 16-point DIF across the row ----
+            // ---- stage 0: radix-2 across the lane pair (b = 0 / 1), twiddle on the odd half ----
             hazard_fence(v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {              // d = 8
-                v2f p = dpp_pair<0x128, 0xF>(v[k], v[k]);
-                v[k] = pk_cmul(v[k] * sig[0] + p, wst[0]);
+            for (int k = 0; k < 8; ++k) {
+                v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);        // quad_perm [1,0,3,2]: lane ^ 1
+                v[k] = pk_cmul(v[k] * sig0 + p, wst0);
             }
-            hazard_fence(v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {              // d = 4: lanes 0-3,8-11 take lane+4, others lane-4
-                v2f p = dpp_pair<0x104, 0x5>(v[k], v[k]);       // row_shl:4 -> lane + 4
-                p = dpp_pair<0x114, 0xA>(p, v[k]);              // row_shr:4 -> lane - 4
-                v[k] = pk_cmul(v[k] * sig[1] + p, wst[1]);
-            }
-            hazard_fence(v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {              // d = 2
-                v2f p = dpp_pair<0x4E, 0xF>(v[k], v[k]);
-                v[k] = pk_cmul(v[k] * sig[2] + p, wst[2]);
-            }
-            hazard_fence(v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {              // d = 1 (no twiddle)
-                v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);
-                v[k] = v[k] * sig[3] + p;
-            }
-            // lane q now holds Z[k1 + 8 bitrev4(q)], k1 = 0..7 of its frame
+            // ---- E: q' <-> k1 through LDS (addresses of stft_wave1024_kernel's E1) ----
+            fft512_exchange1(v, e_wr, e_rd);
+            // ---- pass C: lane l of its frame ends with Z[l + 16 mu] in register mu ----
+            pk_dft8(v);
 
             // ---- strip: Z of the four frames, Z[128] := Z[0] ----
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                strip_wr[i] = v4f{v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y};
-            if (q == 0)
-                scr[fq * kW256StripStride + w256_strip_index(128)] = v[0];
+            for (int mu = 0; mu < 8; ++mu)
+                strip_wr[16 * mu] = v[mu];
+            if (lB == 0)
+                scr[fqB * kW256StripStride + 128] = v[0];
             __builtin_amdgcn_wave_barrier();
             v2f za[5], zb[5];
 #pragma unroll
