@@ -553,7 +553,8 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 // transformed; each wave interleaves its two frames of the chunk.  All complex arithmetic is
 // packed f32 (pk_* helpers above).  ABL is the ablation mask of tools/ablate_w1024.hip (0 in the
 // shipped library): 1 no stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split
-// strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines.
+// strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines,
+// 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80).
 template <int OUT, int ABL = 0, bool WIDE = false>
 __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+    const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (int)(c - c0) & 1;
@@ -686,7 +688,21 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
 #pragma unroll
             for (int kk = 1; kk < 8; ++kk)
                 v[kk] = pk_cmul(v[kk], twB[kk]);
-            if (!(ABL & 2)) {
+            if (ABL & 512) {
+                // E2 through LDS as well (variant timed by tools/ablate_w1024.hip): writer as E1,
+                // reader lane (k1 = L & 7, ka = L >> 3) takes 8 consecutive complex from 66 k1 + 8 ka
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    e1_wr[8 * kk] = v[kk];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v4f qv = e2_rd[i];
+                    v[2 * i] = v2f{qv.x, qv.y};
+                    v[2 * i + 1] = v2f{qv.z, qv.w};
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (!(ABL & 2)) {
                 hazard_fence(v);   // packed asm -> DPP / permlane read
                 exchange_high(v);
             }

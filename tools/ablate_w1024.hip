@@ -86,6 +86,9 @@ int main(int argc, char **argv)
     run<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier");
     run<2 | 4 | 16>(fpw, "no exchanges at all");
     run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)");
+    run<512>(fpw, "E2 through LDS instead of registers");
+    run<512 | 1>(fpw, "E2 through LDS, no global stores");
     run<0>(fpw, "full kernel (again)");
+    run<512>(fpw, "E2 through LDS (again)");
     return 0;
 }
