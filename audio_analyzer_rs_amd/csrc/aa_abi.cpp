@@ -1079,6 +1079,100 @@ int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bin
     return AA_OK;
 }
 
+int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, int64_t n_frames,
+                            int32_t n_bins, float bin_width, float min_freq, float max_freq,
+                            float *out_freq_dev, float *out_score_dev, int32_t *out_count_dev, void *stream)
+{
+    if (!mags_dev || !eff_floor_dev || !out_freq_dev || !out_score_dev || !out_count_dev || n_frames < 0 ||
+        n_bins < 3 || !(bin_width > 0.0f))
+        return fail(AA_ERR_ARG, "aa_tuner_pitches_device: bad argument");
+    if (n_bins > 4097)
+        return fail(AA_ERR_UNSUPPORTED, "aa_tuner_pitches_device: n_bins > 4097 is not built (got %d)", n_bins);
+    AA_HIP(aa::launch_tuner_pitches(mags_dev, eff_floor_dev, n_frames, n_bins, bin_width, min_freq, max_freq,
+                                    out_freq_dev, out_score_dev, out_count_dev, (hipStream_t)stream));
+    return AA_OK;
+}
+
+// PitchTracker (src/audio_io/stft.rs:28-117): sequential hit / miss hysteresis over <= 8 raw
+// pitches per frame - host logic, like in the reference (nothing here is worth a kernel).
+struct aa_pitch_tracker {
+    struct Track {
+        float freq, score;
+        int life;
+    };
+    std::vector<Track> tracks;
+};
+
+int aa_pitch_tracker_create(aa_pitch_tracker **out)
+{
+    if (!out)
+        return fail(AA_ERR_ARG, "aa_pitch_tracker_create: out is NULL");
+    *out = new (std::nothrow) aa_pitch_tracker();
+    return *out ? AA_OK : fail(AA_ERR_NOMEM, "aa_pitch_tracker_create: out of memory");
+}
+
+int aa_pitch_tracker_destroy(aa_pitch_tracker *t)
+{
+    delete t;
+    return AA_OK;
+}
+
+int aa_pitch_tracker_process(aa_pitch_tracker *t, const float *freq_host, const float *score_host,
+                             const int32_t *count_host, const uint8_t *onset_host, int64_t n_frames,
+                             float *out_freq_host, float *out_score_host, int32_t *out_count_host)
+{
+    if (!t || !freq_host || !score_host || !count_host || !out_freq_host || !out_score_host || !out_count_host ||
+        n_frames < 0)
+        return fail(AA_ERR_ARG, "aa_pitch_tracker_process: bad argument");
+    constexpr int kDisplayThreshold = 2, kMaxLife = 3, kCap = AA_PITCH_TRACKS_MAX;
+    constexpr float kTolerance = 0.03f;
+    std::vector<char> matched;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const bool onset = onset_host && onset_host[f] != 0;
+        auto &tr = t->tracks;
+        matched.assign(tr.size(), 0);
+        const int n_raw = std::min<int32_t>(std::max<int32_t>(count_host[f], 0), 8);
+        for (int r = 0; r < n_raw; ++r) {
+            const float raw_freq = freq_host[f * 8 + r], raw_score = score_host[f * 8 + r];
+            bool found = false;
+            for (size_t i = 0; i < tr.size() && !found; ++i) {
+                if (matched[i] || !(std::fabs(tr[i].freq - raw_freq) / tr[i].freq < kTolerance))
+                    continue;
+                // an onset snaps to the new frequency, otherwise the track is EMA-blended
+                tr[i].freq = onset ? raw_freq : tr[i].freq * 0.6f + raw_freq * 0.4f;
+                tr[i].score = raw_score;
+                tr[i].life = std::min(tr[i].life + 1, kMaxLife);
+                matched[i] = 1;
+                found = true;
+            }
+            if (!found) {
+                tr.push_back({raw_freq, raw_score, 1});
+                matched.push_back(1);
+            }
+        }
+        // misses decay (or die at once on an onset), dead tracks are reaped, stable ones emitted
+        int n_out = 0;
+        size_t w = 0;
+        for (size_t i = 0; i < tr.size(); ++i) {
+            if (!matched[i])
+                tr[i].life = onset ? 0 : tr[i].life - 1;
+            if (tr[i].life <= 0)
+                continue;
+            if (tr[i].life >= kDisplayThreshold && n_out < kCap) {
+                out_freq_host[f * kCap + n_out] = tr[i].freq;
+                out_score_host[f * kCap + n_out] = tr[i].score;
+                ++n_out;
+            }
+            tr[w++] = tr[i];
+        }
+        tr.resize(w);
+        for (int i = n_out; i < kCap; ++i)
+            out_freq_host[f * kCap + i] = out_score_host[f * kCap + i] = 0.0f;
+        out_count_host[f] = n_out;
+    }
+    return AA_OK;
+}
+
 // ---------------------------------------------------------------------- sharding --
 int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *f0, int64_t *f1)
 {

@@ -128,6 +128,9 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
                               const float *global_floor, float *state, int initialized, int64_t n_frames,
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
                               int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream);
+hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                                float bin_width, float min_freq, float max_freq, float *out_freq,
+                                float *out_score, int32_t *out_count, hipStream_t stream);
 hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
                               int initialized, float *eff, int64_t n_frames, int n_bins,
                               hipStream_t stream);

@@ -343,6 +343,215 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
     }
 }
 
+// Tuner multi-pitch extraction (src/audio_io/stft.rs:443-620; rest of "next" row f-1 up to the
+// PitchTracker): per frame, peaks above the effective noise floor, parabolic log-magnitude
+// interpolation, harmonic-sum score over <= 14 harmonics, 50 % cutoff, harmonic-ghost suppression,
+// sort by score, 2-bin dedupe, <= 8 notes in [min_freq, max_freq].  Frames are independent: one
+// wave per frame, rows in LDS; peaks / candidates are compacted in bin order with ballots, every
+// peak is scored by one lane with the reference's sequential harmonic walk, the O(C^2) passes
+// (suppression, ranking) run one candidate per lane.  f32 in the reference's operation order;
+// ln / log2 are ocml's logf / log2f (<= 1 ulp, not libm's bits), so scores agree to ~1e-6
+// relative and a decision can flip only on an exact tie.  Equal scores keep bin order (the
+// reference's sort_unstable_by leaves that unspecified).
+constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
+__global__ __launch_bounds__(64) void tuner_pitches_kernel(
+    const float *__restrict__ mags, const float *__restrict__ eff_floor, int64_t n_frames, int n_bins,
+    float bin_width, float min_freq, float max_freq, int min_bin, int max_bin, int max_peaks,
+    float *__restrict__ out_freq, float *__restrict__ out_score, int32_t *__restrict__ out_count)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float pit_lds[];
+    const int lane = threadIdx.x;
+    const int nbp = (n_bins + 3) & ~3;
+    float *m = pit_lds, *nf = m + nbp;
+    float *score = nf + nbp, *frac = score + max_peaks;        // per peak ordinal
+    float *kfrac = frac + max_peaks, *kscore = kfrac + max_peaks;   // kept (unsuppressed) candidates
+    float *sfrac = kscore + max_peaks, *sscore = sfrac + max_peaks; // sorted by score
+    int *peak_bin = reinterpret_cast<int *>(sscore + max_peaks), *cand = peak_bin + max_peaks;
+    unsigned char *is_peak = reinterpret_cast<unsigned char *>(cand + max_peaks);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int half_size = n_bins;
+    for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {
+        __syncthreads();
+        for (int k = lane; k < n_bins; k += 64) {
+            m[k] = mags[t * n_bins + k];
+            nf[k] = eff_floor[t * n_bins + k];
+            is_peak[k] = 0;
+        }
+        __syncthreads();
+        // ---- peaks, compacted in bin order ----
+        int n_peaks = 0;
+        for (int base = min_bin + 1; base < max_bin; base += 64) {
+            const int k = base + lane;
+            const bool pk = k < max_bin && m[k] > nf[k] && m[k] >= m[k - 1] && m[k] >= m[k + 1];
+            const unsigned long long mask = __ballot(pk);
+            if (pk) {
+                is_peak[k] = 1;
+                peak_bin[n_peaks + __popcll(mask & lt)] = k;
+            }
+            n_peaks += __popcll(mask);
+        }
+        __syncthreads();
+        // ---- harmonic-sum score, one peak per lane ----
+        float mx = 0.0f;
+        for (int p = lane; p < n_peaks; p += 64) {
+            const int k = peak_bin[p];
+            const float fund_mag = m[k];
+            float sc = 0.0f, fb = 0.0f;
+            if (!(fund_mag < nf[k] * 5.0f)) {
+                float frac_bin = (float)k;
+                if (k >= 1 && k + 1 < half_size) {
+                    const float y_l = logf(m[k - 1]), y_c = logf(m[k]), y_r = logf(m[k + 1]);
+                    const float denom = y_l - 2.0f * y_c + y_r;
+                    float delta = 0.0f;
+                    if (!(fabsf(denom) < 1e-30f)) {
+                        delta = 0.5f * (y_l - y_r) / denom;
+                        delta = delta < -1.0f ? -1.0f : (delta > 1.0f ? 1.0f : delta);
+                    }
+                    frac_bin = (float)k + delta;
+                }
+                fb = frac_bin;
+                float acc = fund_mag;
+                int last = k, longest_run = 0, current_run = 0, total_harms = 0;
+                for (int n = 2; n <= kMaxHarmonics; ++n) {
+                    const float expected_f = frac_bin * (float)n;
+                    if (expected_f >= (float)half_size)
+                        break;
+                    const float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
+                    int search_start = lo > 0.0f ? (int)lo : 0;
+                    if (search_start < last + 1)
+                        search_start = last + 1;
+                    int search_end = (int)hi;
+                    if (search_end > half_size - 1)
+                        search_end = half_size - 1;
+                    int best_hbin = 0;
+                    float best_mag = 0.0f;
+                    for (int h = search_start; h <= search_end; ++h)
+                        if (is_peak[h] && m[h] > best_mag) {
+                            best_mag = m[h];
+                            best_hbin = h;
+                        }
+                    if (best_hbin != 0) {
+                        acc += best_mag;
+                        last = best_hbin;
+                        current_run += 1;
+                        total_harms += 1;
+                    } else {
+                        if (current_run > longest_run)
+                            longest_run = current_run;
+                        current_run = 0;
+                    }
+                }
+                if (current_run > longest_run)
+                    longest_run = current_run;
+                if (!(longest_run < 3 && fund_mag < 15.0f * nf[k])) {
+                    const float log_score = log2f(0.5f + acc);
+                    const float struct_mult =
+                        (1.0f + (float)longest_run + (float)total_harms / 2.0f) / (1.0f + (float)kMaxHarmonics);
+                    sc = log_score * struct_mult;
+                }
+            }
+            score[p] = sc;
+            frac[p] = fb;
+            mx = fmaxf(mx, sc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        __syncthreads();
+        int n_out = 0;
+        float my_freq = 0.0f, my_score = 0.0f;             // lane i < 8 carries output slot i
+        if (n_peaks > 0 && mx != 0.0f) {
+            const float cutoff = mx * 0.5f;
+            // ---- candidates (score >= cutoff), bin order ----
+            int n_cand = 0;
+            for (int base = 0; base < n_peaks; base += 64) {
+                const int p = base + lane;
+                const bool c = p < n_peaks && score[p] >= cutoff;
+                const unsigned long long mask = __ballot(c);
+                if (c)
+                    cand[n_cand + __popcll(mask & lt)] = p;
+                n_cand += __popcll(mask);
+            }
+            __syncthreads();
+            // ---- harmonic ghosts: one candidate per lane against all others; keep the rest ----
+            int n_kept = 0;
+            for (int base = 0; base < n_cand; base += 64) {
+                const int i = base + lane;
+                bool keep = false;
+                float fi = 0.0f, si = 0.0f;
+                if (i < n_cand) {
+                    fi = frac[cand[i]];
+                    si = score[cand[i]];
+                    const float freq_i = fi * bin_width;
+                    bool suppressed = false;
+                    for (int j = 0; j < n_cand && !suppressed; ++j) {
+                        if (j == i)
+                            continue;
+                        const float freq_j = frac[cand[j]] * bin_width, score_j = score[cand[j]];
+                        const float ratio = freq_i / freq_j;
+                        const float nearest = roundf(ratio);
+                        if (nearest >= 2.0f && nearest <= 5.0f && fabsf(ratio / nearest - 1.0f) < 0.03f &&
+                            si < score_j * 1.05f)
+                            suppressed = true;
+                    }
+                    keep = !suppressed;
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (keep) {
+                    const int pos = n_kept + __popcll(mask & lt);
+                    kfrac[pos] = fi;
+                    kscore[pos] = si;
+                }
+                n_kept += __popcll(mask);
+            }
+            __syncthreads();
+            // ---- descending score, equal scores in bin order: rank = elements that come first ----
+            for (int i = lane; i < n_kept; i += 64) {
+                const float si = kscore[i];
+                int rank = 0;
+                for (int j = 0; j < n_kept; ++j)
+                    rank += (kscore[j] > si || (kscore[j] == si && j < i)) ? 1 : 0;
+                sfrac[rank] = kfrac[i];
+                sscore[rank] = si;
+            }
+            __syncthreads();
+            // ---- 2-bin dedupe in score order, first 8; every lane walks the (short) list ----
+            float acc_frac[kMaxNotes];
+            int n_acc = 0;
+            for (int i = 0; i < n_kept && n_acc < kMaxNotes; ++i) {
+                const float fi = sfrac[i];
+                bool conflict = false;
+#pragma unroll
+                for (int j = 0; j < kMaxNotes; ++j)
+                    if (j < n_acc && fabsf(fi - acc_frac[j]) < 2.0f)
+                        conflict = true;
+                if (!conflict) {
+#pragma unroll
+                    for (int j = 0; j < kMaxNotes; ++j)
+                        if (j == n_acc)
+                            acc_frac[j] = fi;
+                    ++n_acc;
+                    const float freq = fi * bin_width;
+                    if (freq >= min_freq && freq <= max_freq) {
+                        if (lane == n_out) {
+                            my_freq = freq;
+                            my_score = sscore[i];
+                        }
+                        ++n_out;
+                    }
+                }
+            }
+        }
+        if (lane < kMaxNotes) {
+            out_freq[t * kMaxNotes + lane] = my_freq;
+            out_score[t * kMaxNotes + lane] = my_score;
+        }
+        if (lane == 0)
+            out_count[t] = n_out;
+    }
+}
+
 // Tuner front end (src/audio_io/stft.rs:326-367), first stage of "next" row f-1: the variance-
 // aware per-bin noise floor.  It is a recurrence over frames, independent per bin: one lane per
 // bin walks the frames in order with exactly the reference's operation order (contraction off,
@@ -465,6 +674,31 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
     else
         AA_GATES(65);
 #undef AA_GATES
+    return hipGetLastError();
+}
+
+hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                                float bin_width, float min_freq, float max_freq, float *out_freq,
+                                float *out_score, int32_t *out_count, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return hipSuccess;
+    // the reference's bin range (stft.rs:454-455), evaluated in f32 like it
+    int min_bin = (int)ceilf(min_freq / bin_width);
+    if (min_bin < 1)
+        min_bin = 1;
+    int max_bin = (int)floorf(max_freq / bin_width);
+    if (max_bin > n_bins - 2)
+        max_bin = n_bins - 2;
+    const int max_peaks = n_bins / 2 + 2;
+    const int nbp = (n_bins + 3) & ~3;
+    const size_t lds = sizeof(float) * (size_t)(2 * nbp + 8 * max_peaks) + (size_t)nbp;
+    if (lds > 64 * 1024)
+        return hipErrorInvalidValue;
+    int64_t blocks = n_frames < 16384 ? n_frames : 16384;
+    hipLaunchKernelGGL(tuner_pitches_kernel, dim3((unsigned)blocks), dim3(64), lds, stream, mags, eff_floor,
+                       n_frames, n_bins, bin_width, min_freq, max_freq, min_bin, max_bin, max_peaks, out_freq,
+                       out_score, out_count);
     return hipGetLastError();
 }
 

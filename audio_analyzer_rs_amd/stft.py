@@ -208,6 +208,57 @@ def tuner_floor(mags, global_floor, state=None, stream=None):
     return eff, state
 
 
+def tuner_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0, stream=None):
+    """Multi-pitch extraction of the tuner (src/audio_io/stft.rs:443-620) for every frame of a CUDA
+    float32 magnitude spectrogram [frames, bins] and its effective noise floor (tuner_floor).
+    Returns (freq [frames, 8], score [frames, 8], count [frames]) CUDA tensors."""
+    import torch
+
+    lib = _lib.load()
+    nf, nb = mags.shape
+    freq = torch.empty((nf, 8), dtype=torch.float32, device=mags.device)
+    score = torch.empty((nf, 8), dtype=torch.float32, device=mags.device)
+    count = torch.empty(nf, dtype=torch.int32, device=mags.device)
+    st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
+    if nf:
+        _lib.check(lib.aa_tuner_pitches_device(mags.data_ptr(), eff_floor.data_ptr(), nf, nb, float(bin_width),
+                                               float(min_freq), float(max_freq), freq.data_ptr(),
+                                               score.data_ptr(), count.data_ptr(), st))
+    return freq, score, count
+
+
+class PitchTracker:
+    """Mirror of the reference's PitchTracker (src/audio_io/stft.rs:28-117): feed it the per-frame
+    raw pitches of tuner_pitches (numpy arrays on the host), get the stable pitches back."""
+
+    TRACKS_MAX = 32
+
+    def __init__(self):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.aa_pitch_tracker_create(ctypes.byref(h)))
+        self._h = h
+
+    def process(self, freq, score, count, onset=None):
+        freq = np.ascontiguousarray(freq, dtype=np.float32)
+        score = np.ascontiguousarray(score, dtype=np.float32)
+        count = np.ascontiguousarray(count, dtype=np.int32)
+        nf = freq.shape[0]
+        on = None if onset is None else np.ascontiguousarray(onset, dtype=np.uint8)
+        of = np.zeros((nf, self.TRACKS_MAX), np.float32)
+        os_ = np.zeros((nf, self.TRACKS_MAX), np.float32)
+        oc = np.zeros(nf, np.int32)
+        _lib.check(self._lib.aa_pitch_tracker_process(
+            self._h, freq.ctypes.data, score.ctypes.data, count.ctypes.data, None if on is None else on.ctypes.data,
+            nf, of.ctypes.data, os_.ctypes.data, oc.ctypes.data))
+        return of, os_, oc
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.aa_pitch_tracker_destroy(self._h)
+            self._h = None
+
+
 class StftStream:
     """Streaming front end: the ring-buffer ingest of stft.rs:198-201, 240-266 feeding the
     GPU frame loop.  `push(slot)` appends one slot (the reference's are 1024 samples,

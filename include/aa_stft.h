@@ -224,6 +224,36 @@ int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bin
                           const float *global_floor_dev, float *state_dev, int32_t initialized,
                           float *eff_floor_dev, void *stream);
 
+/* ---- tuner: multi-pitch extraction per frame (src/audio_io/stft.rs:443-620) ---- */
+/* STFT::extract_pitches for every frame of a magnitude spectrogram and its effective noise floor
+ * (aa_tuner_floor_device): peaks above the floor in [min_freq, max_freq] (the reference passes
+ * 24 Hz and 10 kHz, stft.rs:173-174; bin_width = sample_rate / n_fft, :320), parabolic
+ * log-magnitude interpolation, harmonic-sum score over up to 14 harmonics, 50 % score cutoff,
+ * harmonic-ghost suppression, descending score, 2-bin dedupe, at most 8 notes.
+ * out_freq_dev / out_score_dev: [n_frames][8] (unused slots 0), out_count_dev: notes per frame.
+ * f32 in the reference's operation order; ln / log2 come from the device math library, so scores
+ * match a CPU evaluation to ~1e-6 relative and a decision can only flip on an exact tie; equal
+ * scores keep ascending bin order (the reference's sort_unstable_by leaves it unspecified).
+ * The PitchTracker hysteresis that follows (stft.rs:28-117) is sequential host logic. */
+int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, int64_t n_frames,
+                            int32_t n_bins, float bin_width, float min_freq, float max_freq,
+                            float *out_freq_dev, float *out_score_dev, int32_t *out_count_dev, void *stream);
+
+/* ---- tuner: PitchTracker hysteresis (src/audio_io/stft.rs:28-117), host side ---- */
+/* Sequential over frames and tiny (<= 8 raw pitches per frame): host logic as in the reference.
+ * A raw pitch within 3 % of an unmatched track updates it (EMA 0.6 / 0.4, or a snap when the
+ * frame carries an onset) and raises its life (max 3); unmatched tracks lose a life (all of it on
+ * an onset); tracks with life >= 2 are emitted.  Inputs: the per-frame arrays of
+ * aa_tuner_pitches_device copied to the host, onset_host[t] != 0 marks a pending onset (NULL =
+ * none).  Outputs: [n_frames][AA_PITCH_TRACKS_MAX] stable (freq, score), unused slots 0. */
+#define AA_PITCH_TRACKS_MAX 32
+typedef struct aa_pitch_tracker aa_pitch_tracker;
+int aa_pitch_tracker_create(aa_pitch_tracker **out);
+int aa_pitch_tracker_destroy(aa_pitch_tracker *t);
+int aa_pitch_tracker_process(aa_pitch_tracker *t, const float *freq_host, const float *score_host,
+                             const int32_t *count_host, const uint8_t *onset_host, int64_t n_frames,
+                             float *out_freq_host, float *out_score_host, int32_t *out_count_host);
+
 /* ---- frame-range sharding (one rank per GPU) --------------- */
 /* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs
  * samples [f0*hop, (f1-1)*hop + n_fft) — a halo of n_fft-hop samples shared with

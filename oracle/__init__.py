@@ -12,10 +12,12 @@ which cannot be built in this image.  The oracle is pinned against a float64
 from .capi import (  # noqa: F401
     Oracle,
     build_oracle,
+    extract_pitches,
     hann_window,
     num_frames,
     onset_flux,
     onset_gates,
+    pitch_tracker,
     rfft_forward,
     rfft_inverse,
     stft,

@@ -64,6 +64,15 @@ class Oracle:
                                         ctypes.POINTER(ctypes.c_int), _f32p, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8), _f32p]
         lib.aao_onset_gates.restype = None
+        lib.aao_extract_pitches.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, _f32p, _f32p,
+                                            ctypes.POINTER(ctypes.c_int32)]
+        lib.aao_extract_pitches.restype = None
+        lib.aao_pitch_tracker.argtypes = [_f32p, _f32p, ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64, _f32p,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.c_int, _f32p, _f32p,
+                                          ctypes.POINTER(ctypes.c_int32)]
+        lib.aao_pitch_tracker.restype = None
         lib.aao_tuner_floor.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_int), _f32p]
         lib.aao_tuner_floor.restype = None
@@ -229,3 +238,39 @@ def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False)
         out["burst_count"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
         out["flags"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _ptr(out["velocity"]))
     return out, st, bool(init.value)
+
+
+def extract_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0):
+    """Multi-pitch extraction of the tuner (src/audio_io/stft.rs:443-620) per frame, sequential f32.
+    Returns (freq [frames, 8], score [frames, 8], count [frames])."""
+    mags = np.ascontiguousarray(mags, dtype=np.float32)
+    eff_floor = np.ascontiguousarray(eff_floor, dtype=np.float32)
+    nf, nb = mags.shape
+    assert eff_floor.shape == mags.shape
+    freq = np.zeros((nf, 8), np.float32)
+    score = np.zeros((nf, 8), np.float32)
+    count = np.zeros(nf, np.int32)
+    Oracle.get().lib.aao_extract_pitches(_ptr(mags), _ptr(eff_floor), nf, nb, bin_width, min_freq, max_freq,
+                                         _ptr(freq), _ptr(score),
+                                         count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return freq, score, count
+
+
+def pitch_tracker(freq, score, count, onset=None, cap=32):
+    """PitchTracker::process (src/audio_io/stft.rs:28-117) over all frames from a fresh tracker.
+    Returns (stable freq [frames, cap], score [frames, cap], count [frames])."""
+    freq = np.ascontiguousarray(freq, dtype=np.float32)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    nf = freq.shape[0]
+    on = None if onset is None else np.ascontiguousarray(onset, dtype=np.uint8)
+    tracks = np.zeros((cap, 3), np.float32)
+    n_tracks = ctypes.c_int(0)
+    of = np.zeros((nf, cap), np.float32)
+    os_ = np.zeros((nf, cap), np.float32)
+    oc = np.zeros(nf, np.int32)
+    Oracle.get().lib.aao_pitch_tracker(
+        _ptr(freq), _ptr(score), count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        None if on is None else on.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), nf, _ptr(tracks),
+        ctypes.byref(n_tracks), cap, _ptr(of), _ptr(os_), oc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return of, os_, oc

@@ -573,6 +573,261 @@ void aao_tuner_floor(const float *mags, int64_t n_frames, int n_bins, const floa
     }
 }
 
+/* ------------------------------------ tuner front: multi-pitch extraction -- */
+
+/* STFT::extract_pitches (src/audio_io/stft.rs:443-620) for every frame: peak picking against the
+ * effective noise floor, parabolic (log-magnitude) interpolation, harmonic-sum scoring over up
+ * to 14 harmonics, 50 % score cutoff, harmonic-ghost suppression, sort by score, 2-bin dedupe,
+ * at most 8 notes inside [min_freq, max_freq].  f32 in the reference's operation order; ln / log2
+ * are libm's logf / log2f.  One deviation, stated: the reference sorts with sort_unstable_by
+ * (order of exactly equal scores unspecified); here equal scores keep ascending bin order.
+ * out_freq / out_score: [n_frames][8], unused slots 0; out_count: notes per frame. */
+#define AAO_MAX_NOTES 8
+#define AAO_MAX_HARMONICS 14
+void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                         float bin_width, float min_freq, float max_freq, float *out_freq,
+                         float *out_score, int32_t *out_count)
+{
+    const int half_size = n_bins;
+    int min_bin = (int)ceilf(min_freq / bin_width);
+    if (min_bin < 1)
+        min_bin = 1;
+    int max_bin = (int)floorf(max_freq / bin_width);
+    if (max_bin > half_size - 2)
+        max_bin = half_size - 2;
+    unsigned char *is_peak = (unsigned char *)malloc((size_t)half_size);
+    int *peak_bins = (int *)malloc(sizeof(int) * (size_t)half_size);
+    float *scores = (float *)malloc(sizeof(float) * (size_t)half_size);
+    float *frac_bins = (float *)malloc(sizeof(float) * (size_t)half_size);
+    int *cand = (int *)malloc(sizeof(int) * (size_t)half_size);
+    int *kept = (int *)malloc(sizeof(int) * (size_t)half_size);
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const float *m = mags + t * (int64_t)n_bins, *nf = eff_floor + t * (int64_t)n_bins;
+        float *of = out_freq + t * AAO_MAX_NOTES, *os = out_score + t * AAO_MAX_NOTES;
+        for (int i = 0; i < AAO_MAX_NOTES; ++i)
+            of[i] = os[i] = 0.0f;
+        out_count[t] = 0;
+        if (min_bin >= max_bin)
+            continue;
+        memset(is_peak, 0, (size_t)half_size);
+        int n_peaks = 0;
+        for (int k = min_bin + 1; k < max_bin; ++k)
+            if (m[k] > nf[k] && m[k] >= m[k - 1] && m[k] >= m[k + 1]) {
+                is_peak[k] = 1;
+                peak_bins[n_peaks++] = k;
+            }
+        if (n_peaks == 0)
+            continue;
+        for (int p = 0; p < n_peaks; ++p) {
+            const int k = peak_bins[p];
+            const float fund_mag = m[k];
+            scores[k] = 0.0f;
+            frac_bins[k] = 0.0f;
+            if (fund_mag < nf[k] * 5.0f)
+                continue;
+            float frac_bin = (float)k;
+            if (k >= 1 && k + 1 < half_size) {
+                const float y_l = logf(m[k - 1]), y_c = logf(m[k]), y_r = logf(m[k + 1]);
+                const float denom = y_l - 2.0f * y_c + y_r;
+                float delta = 0.0f;
+                if (!(fabsf(denom) < 1e-30f)) {
+                    delta = 0.5f * (y_l - y_r) / denom;
+                    delta = delta < -1.0f ? -1.0f : (delta > 1.0f ? 1.0f : delta);
+                }
+                frac_bin = (float)k + delta;
+            }
+            frac_bins[k] = frac_bin;
+            float score = fund_mag;
+            int last = k, longest_run = 0, current_run = 0, total_harms = 0;
+            for (int n = 2; n <= AAO_MAX_HARMONICS; ++n) {
+                const float expected_f = frac_bin * (float)n;
+                if (expected_f >= (float)half_size)
+                    break;
+                float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
+                int search_start = lo > 0.0f ? (int)lo : 0;
+                if (search_start < last + 1)
+                    search_start = last + 1;
+                int search_end = (int)hi;
+                if (search_end > half_size - 1)
+                    search_end = half_size - 1;
+                int best_hbin = 0;
+                float best_mag = 0.0f;
+                for (int h = search_start; h <= search_end; ++h)
+                    if (is_peak[h] && m[h] > best_mag) {
+                        best_mag = m[h];
+                        best_hbin = h;
+                    }
+                if (best_hbin != 0) {
+                    score += best_mag;
+                    last = best_hbin;
+                    current_run += 1;
+                    total_harms += 1;
+                } else {
+                    if (current_run > longest_run)
+                        longest_run = current_run;
+                    current_run = 0;
+                }
+            }
+            if (current_run > longest_run)
+                longest_run = current_run;
+            if (longest_run < 3 && fund_mag < 15.0f * nf[k]) {
+                scores[k] = 0.0f;
+            } else {
+                const float log_score = log2f(0.5f + score);
+                const float struct_mult =
+                    (1.0f + (float)longest_run + (float)total_harms / 2.0f) / (1.0f + (float)AAO_MAX_HARMONICS);
+                scores[k] = log_score * struct_mult;
+            }
+        }
+        float max_score = 0.0f;
+        for (int p = 0; p < n_peaks; ++p)
+            max_score = fmaxf(max_score, scores[peak_bins[p]]);
+        if (max_score == 0.0f)
+            continue;
+        const float cutoff = max_score * 0.5f;
+        int n_cand = 0;
+        for (int p = 0; p < n_peaks; ++p)
+            if (scores[peak_bins[p]] >= cutoff)
+                cand[n_cand++] = peak_bins[p];
+        /* harmonic ghosts: freq_i ~ N freq_j (N = 2..5) with a score below 1.05 x that of j */
+        int n_kept = 0;
+        for (int i = 0; i < n_cand; ++i) {
+            const float freq_i = frac_bins[cand[i]] * bin_width, score_i = scores[cand[i]];
+            int suppressed = 0;
+            for (int j = 0; j < n_cand && !suppressed; ++j) {
+                if (i == j)
+                    continue;
+                const float freq_j = frac_bins[cand[j]] * bin_width, score_j = scores[cand[j]];
+                const float ratio = freq_i / freq_j;
+                const float nearest = roundf(ratio);
+                if (nearest >= 2.0f && nearest <= 5.0f && fabsf(ratio / nearest - 1.0f) < 0.03f &&
+                    score_i < score_j * 1.05f)
+                    suppressed = 1;
+            }
+            if (!suppressed)
+                kept[n_kept++] = cand[i];
+        }
+        /* descending score, stable (insertion sort) */
+        for (int i = 1; i < n_kept; ++i) {
+            const int b = kept[i];
+            int j = i - 1;
+            while (j >= 0 && scores[kept[j]] < scores[b]) {
+                kept[j + 1] = kept[j];
+                --j;
+            }
+            kept[j + 1] = b;
+        }
+        int acc[AAO_MAX_NOTES], n_acc = 0, n_dedup = 0;
+        for (int i = 0; i < n_kept && n_dedup < AAO_MAX_NOTES; ++i) {
+            const float frac_i = frac_bins[kept[i]];
+            int conflict = 0;
+            for (int j = 0; j < n_acc; ++j)
+                if (fabsf(frac_i - frac_bins[acc[j]]) < 2.0f)
+                    conflict = 1;
+            if (!conflict) {
+                acc[n_acc++] = kept[i];
+                ++n_dedup;
+            }
+        }
+        int n_out = 0;
+        for (int i = 0; i < n_acc; ++i) {
+            const float freq = frac_bins[acc[i]] * bin_width;
+            if (freq >= min_freq && freq <= max_freq) {
+                of[n_out] = freq;
+                os[n_out] = scores[acc[i]];
+                ++n_out;
+            }
+        }
+        out_count[t] = n_out;
+    }
+    free(is_peak);
+    free(peak_bins);
+    free(scores);
+    free(frac_bins);
+    free(cand);
+    free(kept);
+}
+
+/* PitchTracker::process (src/audio_io/stft.rs:28-117) over a sequence of frames: hit / miss
+ * hysteresis on note tracks (display_threshold 2, max_life 3, tolerance 3 %), EMA-blended or
+ * (on an onset) snapped frequencies.  tracks: [cap][3] floats {freq, score, life}, *n_tracks in /
+ * out; out_*: [n_frames][cap] stable pitches per frame. */
+void aao_pitch_tracker(const float *freq, const float *score, const int32_t *count, const uint8_t *onset,
+                       int64_t n_frames, float *tracks, int *n_tracks, int cap, float *out_freq,
+                       float *out_score, int32_t *out_count)
+{
+    const int display_threshold = 2, max_life = 3;
+    const float tolerance = 0.03f;
+    float *tf = (float *)malloc(sizeof(float) * (size_t)(cap + 8)), *ts = (float *)malloc(sizeof(float) * (size_t)(cap + 8));
+    int *life = (int *)malloc(sizeof(int) * (size_t)(cap + 8));
+    unsigned char *matched = (unsigned char *)malloc((size_t)(cap + 8));
+    int n = *n_tracks;
+    for (int i = 0; i < n; ++i) {
+        tf[i] = tracks[3 * i];
+        ts[i] = tracks[3 * i + 1];
+        life[i] = (int)tracks[3 * i + 2];
+    }
+    for (int64_t t = 0; t < n_frames; ++t) {
+        const int is_onset = onset ? onset[t] != 0 : 0;
+        memset(matched, 0, (size_t)(cap + 8));
+        for (int r = 0; r < count[t] && r < 8; ++r) {
+            const float raw_freq = freq[t * 8 + r], raw_score = score[t * 8 + r];
+            int found = 0;
+            for (int i = 0; i < n; ++i) {
+                if (matched[i])
+                    continue;
+                if (fabsf(tf[i] - raw_freq) / tf[i] < tolerance) {
+                    tf[i] = is_onset ? raw_freq : tf[i] * 0.6f + raw_freq * 0.4f;
+                    ts[i] = raw_score;
+                    life[i] = life[i] + 1 < max_life ? life[i] + 1 : max_life;
+                    matched[i] = 1;
+                    found = 1;
+                    break;
+                }
+            }
+            if (!found && n < cap + 8) {
+                tf[n] = raw_freq;
+                ts[n] = raw_score;
+                life[n] = 1;
+                matched[n] = 1;
+                ++n;
+            }
+        }
+        int n_out = 0, w = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!matched[i])
+                life[i] = is_onset ? 0 : life[i] - 1;
+            if (life[i] <= 0)
+                continue;                     /* destroyed */
+            if (life[i] >= display_threshold && n_out < cap) {
+                out_freq[t * cap + n_out] = tf[i];
+                out_score[t * cap + n_out] = ts[i];
+                ++n_out;
+            }
+            tf[w] = tf[i];
+            ts[w] = ts[i];
+            life[w] = life[i];
+            ++w;
+        }
+        n = w;
+        for (int i = n_out; i < cap; ++i)
+            out_freq[t * cap + i] = out_score[t * cap + i] = 0.0f;
+        out_count[t] = n_out;
+    }
+    if (n > cap)
+        n = cap;
+    for (int i = 0; i < n; ++i) {
+        tracks[3 * i] = tf[i];
+        tracks[3 * i + 1] = ts[i];
+        tracks[3 * i + 2] = (float)life[i];
+    }
+    *n_tracks = n;
+    free(tf);
+    free(ts);
+    free(life);
+    free(matched);
+}
+
 /* ------------------------------------------------------ synthetic signals -- */
 
 /* LCG of the reference's metronome noise tick (src/generators/metronome.rs:56-57):

@@ -396,6 +396,30 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
     assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32))
 
 
+def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
+    """Rest of "next" row f-1 up to the PitchTracker: multi-pitch extraction (stft.rs:443-620) on
+    the tuner geometry, fed with the GPU magnitudes and effective floor.  Note counts, order and
+    the integer decisions agree with the sequential restatement; frequencies and scores to 1e-5
+    relative (the device's logf / log2f are not libm's bits: a decision may flip on an exact tie,
+    so a frame in a thousand may differ)."""
+    from test_oracle import _chord_signal
+
+    sr, n, hop = 48000, 2048, 512
+    x = np.concatenate([_chord_signal(seed=21), aa.signals.synth_corpus(5, 3 * sr)[: 3 * sr]]).astype(np.float32)
+    mags = aa.Stft(n, hop, output="mag")(torch_mod.from_numpy(x).cuda())
+    nf, nb = mags.shape
+    gf = torch_mod.full((nf,), float(10.0 ** (-60.0 / 20.0) * nb / 2.0), device="cuda")
+    eff, _ = aa.tuner_floor(mags, gf)
+    freq, score, count = aa.tuner_pitches(mags, eff, sr / n)
+    rf, rs, rc = oracle_mod.extract_pitches(mags.cpu().numpy(), eff.cpu().numpy(), sr / n)
+    freq, score, count = freq.cpu().numpy(), score.cpu().numpy(), count.cpu().numpy()
+    same = count == rc
+    assert same.mean() > 0.999 and int(rc.max()) >= 3 and (rc > 0).mean() > 0.5
+    assert np.allclose(freq[same], rf[same], rtol=1e-5, atol=0.0)
+    assert np.allclose(score[same], rs[same], rtol=1e-5, atol=1e-6)
+    assert np.all(freq[np.arange(8)[None, :] >= count[:, None]] == 0.0)
+
+
 def test_tuner_noise_floor_bit_exact(aa, oracle_mod, torch_mod):
     """First stage of "next" row f-1: the tuner's per-bin adaptive noise floor
     (stft.rs:326-367) on the tuner geometry — a recurrence, evaluated in the reference's

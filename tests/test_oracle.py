@@ -155,6 +155,70 @@ def test_onset_gates_restatement(oracle_mod):
     assert np.array_equal(s2, st)
 
 
+def _chord_signal(seconds=3.0, sr=48000, seed=3):
+    """Two sustained harmonic notes (A3, E4), then a third (C#5) joins; low noise."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * sr)
+    t = np.arange(n) / sr
+    x = (1e-3 * rng.standard_normal(n)).astype(np.float32)
+    for f0, amp, start in ((220.0, 0.3, 0.0), (329.63, 0.2, 0.0), (554.37, 0.25, seconds / 2)):
+        gate = (t >= start).astype(np.float32)
+        for h in range(1, 9):
+            x += (gate * amp / h * np.sin(2 * np.pi * f0 * h * t)).astype(np.float32)
+    return x
+
+
+def test_extract_pitches_restatement(oracle_mod):
+    # stft.rs:443-620 on the tuner geometry: the notes of a chord come out, strongest first,
+    # harmonics are not reported as notes
+    sr = 48000
+    x = _chord_signal()
+    mags = oracle_mod.stft(x, 2048, 512, kind="mag")
+    nb = mags.shape[1]
+    eff, _, _ = oracle_mod.tuner_floor(mags, np.float32(10.0 ** (-60.0 / 20.0) * nb / 2.0))
+    freq, score, count = oracle_mod.extract_pitches(mags, eff, sr / 2048.0)
+    early, late = slice(20, 120), slice(160, 270)
+    assert np.all(count[early] == 2) and np.all(count[late] == 3)
+    for sl, notes in ((early, (220.0, 329.63)), (late, (220.0, 329.63, 554.37))):
+        got = np.sort(freq[sl, :len(notes)], axis=1)
+        assert np.all(np.abs(got / np.array(notes, np.float32) - 1.0) < 5e-3)
+    assert np.all(np.diff(score[late, :3], axis=1) <= 0.0)              # descending score
+    assert np.all(freq[np.arange(8)[None, :] >= count[:, None]] == 0.0)  # unused slots stay 0
+    # silence: nothing above the floor
+    f0, s0, c0 = oracle_mod.extract_pitches(np.full((4, nb), 1e-4, np.float32), np.full((4, nb), 1e-2, np.float32),
+                                            sr / 2048.0)
+    assert np.all(c0 == 0) and np.all(f0 == 0.0)
+
+
+def test_pitch_tracker_host_matches_restatement(oracle_mod):
+    """PitchTracker (stft.rs:28-117) is sequential host logic on <= 8 raw pitches per frame: the
+    product's C++ version (aa_pitch_tracker_*, no GPU involved) against the C restatement,
+    bit-exact, with and without onsets; plus the hysteresis itself."""
+    import audio_analyzer_rs_amd as aa
+
+    sr = 48000
+    x = _chord_signal()
+    mags = oracle_mod.stft(x, 2048, 512, kind="mag")
+    nb = mags.shape[1]
+    eff, _, _ = oracle_mod.tuner_floor(mags, np.float32(10.0 ** (-60.0 / 20.0) * nb / 2.0))
+    freq, score, count = oracle_mod.extract_pitches(mags, eff, sr / 2048.0)
+    rng = np.random.default_rng(0)
+    drop = rng.random(len(count)) < 0.15                   # missed detections exercise the life counter
+    count = np.where(drop, 0, count).astype(np.int32)
+    onset = (rng.random(len(count)) < 0.03).astype(np.uint8)
+    for on in (None, onset):
+        rf, rs, rc = oracle_mod.pitch_tracker(freq, score, count, on)
+        trk = aa.PitchTracker()
+        cut = 97                                           # two calls carry the tracks across
+        f1, s1, c1 = trk.process(freq[:cut], score[:cut], count[:cut], None if on is None else on[:cut])
+        f2, s2, c2 = trk.process(freq[cut:], score[cut:], count[cut:], None if on is None else on[cut:])
+        assert np.array_equal(np.concatenate([c1, c2]), rc)
+        assert np.array_equal(np.concatenate([f1, f2]), rf) and np.array_equal(np.concatenate([s1, s2]), rs)
+    rf, rs, rc = oracle_mod.pitch_tracker(freq, score, count, None)
+    assert rc[0] == 0 and rc.max() >= 3                     # a note needs two hits before it shows
+    assert np.all(np.abs(rf[150:, 0][rc[150:] > 0] / 220.0 - 1.0) < 0.02)
+
+
 def test_tuner_floor_restatement(oracle_mod):
     # stft.rs:326-367 — first frame initialises, a steady loud bin freezes, quiet bins release
     nb = 4

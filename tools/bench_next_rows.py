@@ -38,3 +38,5 @@ nf, nb = mags.shape
 gf = torch.full((nf,), float(10.0 ** (-60 / 20.0) * nb / 2.0), device="cuda")
 print(f"tuner geometry 2048/512: {nf} frames x {nb} bins")
 print(f"  tuner_floor  {timed(lambda: aa.tuner_floor(mags, gf)) * 1e3:9.3f} ms")
+eff, _ = aa.tuner_floor(mags, gf)
+print(f"  tuner_pitches {timed(lambda: aa.tuner_pitches(mags, eff, 48000 / 2048)) * 1e3:8.3f} ms")
