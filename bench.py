@@ -123,11 +123,18 @@ def main():
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AA_BENCH_REHEARSAL=1 (development only): several ranks share the GPUs of a smaller box and
+    # rendezvous over gloo, to exercise the N > 1 code path where no N-GPU node is available.
+    rehearsal = os.environ.get("AA_BENCH_REHEARSAL", "0") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- this rank's shard of the N x 10 min corpus -------------------------------
     total_samples = world * SAMPLES_PER_RANK
@@ -172,7 +179,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -202,7 +209,7 @@ def main():
                         f"10 min synthetic 48 kHz mono f32 per GPU ({nf} frames/GPU)",
             "n_fft": N_FFT, "hop": HOP, "output": args.output,
             "frames_total": total_frames, "samples_per_gpu": int(shard.local_samples),
-            "parallelism": f"frame-range shards x{world}, outputs stay sharded",
+            "parallelism": f"frame-range shards x{world}, outputs stay sharded" + (" (REHEARSAL: ranks share GPUs, gloo)" if rehearsal else ""),
             "kernel": plan.kernel,
         },
         "roofline": {
