@@ -106,6 +106,14 @@ SIGNATURES = {
     "aa_tuner_pitches_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_onset_flux_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                  ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
+    "aa_onset_gates_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                   ctypes.c_int32] + [ctypes.c_void_p] * 12),
+    "aa_tuner_floor_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_void_p]),
     "aa_pitch_tracker_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "aa_pitch_tracker_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_pitch_tracker_process": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

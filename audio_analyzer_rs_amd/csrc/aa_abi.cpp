@@ -1093,6 +1093,52 @@ int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, i
     return AA_OK;
 }
 
+// ---- batches of independent streams (the recurrences above parallelise across streams) ----
+int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                               int64_t n_frames_total, int32_t n_bins, const float *prev_rows_dev,
+                               float *flux_dev, float *energy_dev, void *stream)
+{
+    if (!mags_dev || !frame_offsets_dev || !flux_dev || !energy_dev || n_streams < 1 || n_frames_total < 0 ||
+        n_bins < 2)
+        return fail(AA_ERR_ARG, "aa_onset_flux_batch_device: bad argument");
+    AA_HIP(aa::launch_onset_flux(mags_dev, prev_rows_dev, flux_dev, energy_dev, n_frames_total, n_bins,
+                                 (hipStream_t)stream, frame_offsets_dev, n_streams));
+    return AA_OK;
+}
+
+int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                                int64_t n_frames_total, int32_t n_bins, const float *flux_dev,
+                                const float *energy_dev, const float *global_floor_dev, float *state_dev,
+                                const int32_t *initialized_dev, float *out_flux_dev, float *out_ema_dev,
+                                float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                                float *out_velocity_dev, void *stream)
+{
+    if (!mags_dev || !frame_offsets_dev || !flux_dev || !energy_dev || !global_floor_dev || !state_dev ||
+        !out_flux_dev || !out_ema_dev || !out_excess_dev || !out_count_dev || !out_flags_dev ||
+        !out_velocity_dev || n_streams < 1 || n_frames_total < 0 || n_bins < 1)
+        return fail(AA_ERR_ARG, "aa_onset_gates_batch_device: bad argument");
+    if (n_bins > 4160)
+        return fail(AA_ERR_UNSUPPORTED, "aa_onset_gates_batch_device: n_bins > 4160 is not built (got %d)", n_bins);
+    AA_HIP(aa::launch_onset_gates(mags_dev, flux_dev, energy_dev, global_floor_dev, state_dev, 0, n_frames_total,
+                                  n_bins, out_flux_dev, out_ema_dev, out_excess_dev, out_count_dev, out_flags_dev,
+                                  out_velocity_dev, (hipStream_t)stream, frame_offsets_dev, initialized_dev,
+                                  n_streams));
+    return AA_OK;
+}
+
+int aa_tuner_floor_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                                int64_t n_frames_total, int32_t n_bins, const float *global_floor_dev,
+                                float *state_dev, const int32_t *initialized_dev, float *eff_floor_dev,
+                                void *stream)
+{
+    if (!mags_dev || !frame_offsets_dev || !global_floor_dev || !state_dev || !eff_floor_dev || n_streams < 1 ||
+        n_streams > 65535 || n_frames_total < 0 || n_bins < 1)
+        return fail(AA_ERR_ARG, "aa_tuner_floor_batch_device: bad argument");
+    AA_HIP(aa::launch_tuner_floor(mags_dev, global_floor_dev, state_dev, 0, eff_floor_dev, n_frames_total, n_bins,
+                                  (hipStream_t)stream, frame_offsets_dev, initialized_dev, n_streams));
+    return AA_OK;
+}
+
 // PitchTracker (src/audio_io/stft.rs:28-117): sequential hit / miss hysteresis over <= 8 raw
 // pitches per frame - host logic, like in the reference (nothing here is worth a kernel).
 struct aa_pitch_tracker {

@@ -122,18 +122,24 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
 hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
                             float *C, int64_t n_rows, int K, int n_cols, int n_pad, float log_floor,
                             hipStream_t stream);
+// The three recurrence / per-frame post-ops take an optional batch description: frame_offsets
+// [n_streams + 1] (device) of streams concatenated along the frame axis; null = one stream.
 hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
-                             int64_t n_frames, int n_bins, hipStream_t stream);
+                             int64_t n_frames, int n_bins, hipStream_t stream,
+                             const int64_t *offsets = nullptr, int n_streams = 1);
 hipError_t launch_onset_gates(const float *mags, const float *flux, const float *energy,
                               const float *global_floor, float *state, int initialized, int64_t n_frames,
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
-                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream);
+                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream,
+                              const int64_t *offsets = nullptr, const int32_t *init_flags = nullptr,
+                              int n_streams = 1);
 hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
                                 float bin_width, float min_freq, float max_freq, float *out_freq,
                                 float *out_score, int32_t *out_count, hipStream_t stream);
 hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
                               int initialized, float *eff, int64_t n_frames, int n_bins,
-                              hipStream_t stream);
+                              hipStream_t stream, const int64_t *offsets = nullptr,
+                              const int32_t *init_flags = nullptr, int n_streams = 1);
 hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int channels,
                           hipStream_t stream);
 

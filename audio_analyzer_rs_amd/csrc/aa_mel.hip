@@ -126,18 +126,35 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float *__rest
 // per frame the 3-bin-smoothed, frequency-weighted positive spectral flux against the previous
 // frame's magnitudes and the frame energy.  One wave per frame; the reference's running f32
 // sums become wave reductions (different summation order: tolerance, not bit-exact).
+// offsets (nullable): frame_offsets[n_streams + 1] of concatenated streams; the first frame of a
+// stream takes prev0 + s * n_bins (or zeros) as its previous row instead of the row before it.
 __global__ __launch_bounds__(256) void onset_flux_kernel(const float *__restrict__ mags,
                                                          const float *__restrict__ prev0,
                                                          float *__restrict__ flux,
                                                          float *__restrict__ energy, int64_t n_frames,
-                                                         int n_bins)
+                                                         int n_bins, const int64_t *__restrict__ offsets,
+                                                         int n_streams)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t t = wave0; t < n_frames; t += nwaves) {
         const float *m = mags + t * n_bins;
-        const float *pv = t == 0 ? prev0 : m - n_bins;
+        const float *pv = m - n_bins;
+        if (offsets) {
+            int lo = 0, hi = n_streams;              // last stream whose first frame is <= t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (offsets[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            if (offsets[lo] == t)
+                pv = prev0 ? prev0 + (int64_t)lo * n_bins : nullptr;
+        } else if (t == 0) {
+            pv = prev0;
+        }
         float fl = 0.0f, en = 0.0f;
         for (int i = lane; i < n_bins; i += 64) {
             const float mag = m[i];
@@ -195,11 +212,28 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
     const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
     int n_bins, int frames_per_block, float *__restrict__ out_flux, float *__restrict__ out_ema,
     float *__restrict__ out_excess, int32_t *__restrict__ out_count, uint8_t *__restrict__ out_flags,
-    float *__restrict__ out_velocity)
+    float *__restrict__ out_velocity, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags)
 {
 #pragma clang fp contract(off)
     extern __shared__ float gate_lds[];
     const int lane = threadIdx.x;
+    if (offsets) {
+        // batch: workgroup s walks stream s = frames [offsets[s], offsets[s+1]) of the concatenated arrays
+        const int64_t f0 = offsets[blockIdx.x];
+        n_frames = offsets[blockIdx.x + 1] - f0;
+        mags += f0 * n_bins;
+        flux += f0;
+        energy += f0;
+        global_floor += f0;
+        out_flux += f0;
+        out_ema += f0;
+        out_excess += f0;
+        out_count += f0;
+        out_flags += f0;
+        out_velocity += f0;
+        state += (int64_t)blockIdx.x * (n_bins + 3);
+        initialized = init_flags ? init_flags[blockIdx.x] : 0;
+    }
     float *blk = gate_lds;                           // frames_per_block rows of magnitudes (+ one pad row)
     const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
     const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
@@ -561,12 +595,23 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
                                                          const float *__restrict__ global_floor,
                                                          float *__restrict__ state, int initialized,
                                                          float *__restrict__ eff, int64_t n_frames,
-                                                         int n_bins)
+                                                         int n_bins, const int64_t *__restrict__ offsets,
+                                                         const int32_t *__restrict__ init_flags)
 {
 #pragma clang fp contract(off)
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n_bins)
         return;
+    if (offsets) {
+        // batch: blockIdx.y walks stream s = frames [offsets[s], offsets[s+1]) of the concatenated arrays
+        const int64_t f0 = offsets[blockIdx.y];
+        n_frames = offsets[blockIdx.y + 1] - f0;
+        mags += f0 * n_bins;
+        eff += f0 * n_bins;
+        global_floor += f0;
+        state += (int64_t)blockIdx.y * 3 * n_bins;
+        initialized = init_flags ? init_flags[blockIdx.y] : 0;
+    }
     const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
     const float VOL_MEMORY = 0.75f, NOTE_RATIO = 1.5f, NOTE_VOL_MAX = 0.15f;
     float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
@@ -635,7 +680,8 @@ hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float 
 }
 
 hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux, float *energy,
-                             int64_t n_frames, int n_bins, hipStream_t stream)
+                             int64_t n_frames, int n_bins, hipStream_t stream, const int64_t *offsets,
+                             int n_streams)
 {
     if (n_frames <= 0)
         return hipSuccess;
@@ -643,16 +689,17 @@ hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux,
     if (blocks > 8192)
         blocks = 8192;
     hipLaunchKernelGGL(onset_flux_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mags, prev0, flux,
-                       energy, n_frames, n_bins);
+                       energy, n_frames, n_bins, offsets, n_streams);
     return hipGetLastError();
 }
 
 hipError_t launch_onset_gates(const float *mags, const float *flux, const float *energy,
                               const float *global_floor, float *state, int initialized, int64_t n_frames,
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
-                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream)
+                              int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream,
+                              const int64_t *offsets, const int32_t *init_flags, int n_streams)
 {
-    if (n_frames <= 0)
+    if (n_frames <= 0 || n_streams <= 0)
         return hipSuccess;
     if (n_bins < 1 || n_bins > 64 * kGatePrefetchRegs)
         return hipErrorInvalidValue;
@@ -662,9 +709,9 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
     const size_t lds = sizeof(float) * (size_t)((fpb + 1) * n_bins);   // + the pad row read one frame ahead
     const int bpl = (n_bins + 63) / 64;
 #define AA_GATES(B)                                                                                      \
-    hipLaunchKernelGGL(onset_gates_kernel<B>, dim3(1), dim3(64), lds, stream, mags, flux, energy,        \
-                       global_floor, state, initialized, n_frames, n_bins, fpb, out_flux, out_ema,       \
-                       out_excess, out_count, out_flags, out_velocity)
+    hipLaunchKernelGGL(onset_gates_kernel<B>, dim3((unsigned)n_streams), dim3(64), lds, stream, mags, flux, \
+                       energy, global_floor, state, initialized, n_frames, n_bins, fpb, out_flux, out_ema,  \
+                       out_excess, out_count, out_flags, out_velocity, offsets, init_flags)
     if (bpl <= 3)
         AA_GATES(3);        // 129 bins: the onset geometry (onset.rs:122-125)
     else if (bpl <= 9)
@@ -704,12 +751,12 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
 
 hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
                               int initialized, float *eff, int64_t n_frames, int n_bins,
-                              hipStream_t stream)
+                              hipStream_t stream, const int64_t *offsets, const int32_t *init_flags, int n_streams)
 {
-    if (n_frames <= 0)
+    if (n_frames <= 0 || n_streams <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(tuner_floor_kernel, dim3((unsigned)((n_bins + 63) / 64)), dim3(64), 0, stream, mags,
-                       global_floor, state, initialized, eff, n_frames, n_bins);
+    hipLaunchKernelGGL(tuner_floor_kernel, dim3((unsigned)((n_bins + 63) / 64), (unsigned)n_streams), dim3(64), 0,
+                       stream, mags, global_floor, state, initialized, eff, n_frames, n_bins, offsets, init_flags);
     return hipGetLastError();
 }
 

@@ -133,9 +133,24 @@ def downmix(interleaved, channels, stream=None):
     return out
 
 
-def onset_flux(mags, prev_row=None, stream=None):
+def _offsets_arg(offsets, nf):
+    """Validate a batch description: CUDA int64 [n_streams + 1], 0 .. total frames."""
+    import torch
+
+    if not (offsets.is_cuda and offsets.dtype == torch.int64 and offsets.dim() == 1 and offsets.is_contiguous()
+            and offsets.numel() >= 2):
+        raise _lib.AaError(_lib.AA_ERR_ARG, "offsets must be a contiguous CUDA int64 vector [n_streams + 1]")
+    host = offsets.cpu()
+    if int(host[0]) != 0 or int(host[-1]) != nf or bool((host[1:] < host[:-1]).any()):
+        raise _lib.AaError(_lib.AA_ERR_ARG, "offsets must ascend from 0 to the number of frames")
+    return offsets.numel() - 1
+
+
+def onset_flux(mags, prev_row=None, stream=None, offsets=None):
     """Spectral flux and frame energy of the onset detector's front end
     (src/analysis/onset.rs:261-291) for a CUDA float32 magnitude spectrogram [frames, bins].
+    offsets (CUDA int64 [n_streams + 1]): the frames are that many independent streams laid end to
+    end; prev_row is then [n_streams, bins] (or None).
     Returns (flux, energy), two CUDA float32 vectors of length frames."""
     import torch
 
@@ -146,7 +161,12 @@ def onset_flux(mags, prev_row=None, stream=None):
     flux = torch.empty(nf, dtype=torch.float32, device=mags.device)
     energy = torch.empty(nf, dtype=torch.float32, device=mags.device)
     st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
-    if nf:
+    if nf and offsets is not None:
+        ns = _offsets_arg(offsets, nf)
+        _lib.check(lib.aa_onset_flux_batch_device(mags.data_ptr(), offsets.data_ptr(), ns, nf, nb,
+                                                  prev_row.data_ptr() if prev_row is not None else None,
+                                                  flux.data_ptr(), energy.data_ptr(), st))
+    elif nf:
         _lib.check(lib.aa_onset_flux_device(mags.data_ptr(), nf, nb,
                                             prev_row.data_ptr() if prev_row is not None else None,
                                             flux.data_ptr(), energy.data_ptr(), st))
@@ -156,20 +176,23 @@ def onset_flux(mags, prev_row=None, stream=None):
 ONSET_FLAG_FLUX, ONSET_FLAG_BURST, ONSET_FLAG_DETECTED, ONSET_FLAG_ENERGY_RISING, ONSET_FLAG_FIRED = 1, 2, 4, 8, 16
 
 
-def onset_gates(mags, flux, energy, global_floor, state=None, stream=None):
+def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offsets=None):
     """The onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
     531-535): burst floor, silence gate, energy EMA, FluxTracker, combined trigger, velocity,
     frames_since_onset gate (calibrated transport, no metronome tick).  All arguments are CUDA
     tensors: mags float32 [frames, bins]; flux, energy, global_floor float32 [frames].  state:
     None for a fresh detector, or the [bins + 3] tensor returned by a previous call.
+    offsets (CUDA int64 [n_streams + 1]): independent streams laid end to end, one wave each; state
+    is then [n_streams, bins + 3].
     Returns (dict of per-frame tensors, state)."""
     import torch
 
     lib = _lib.load()
     nf, nb = mags.shape
     initialized = state is not None
+    ns = _offsets_arg(offsets, nf) if offsets is not None else None
     if state is None:
-        state = torch.zeros(nb + 3, dtype=torch.float32, device=mags.device)
+        state = torch.zeros(nb + 3 if ns is None else (ns, nb + 3), dtype=torch.float32, device=mags.device)
     out = {
         "flux": torch.empty(nf, dtype=torch.float32, device=mags.device),
         "energy_ema": torch.empty(nf, dtype=torch.float32, device=mags.device),
@@ -179,7 +202,14 @@ def onset_gates(mags, flux, energy, global_floor, state=None, stream=None):
         "velocity": torch.empty(nf, dtype=torch.float32, device=mags.device),
     }
     st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
-    if nf:
+    if nf and ns is not None:
+        init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
+        _lib.check(lib.aa_onset_gates_batch_device(
+            mags.data_ptr(), offsets.data_ptr(), ns, nf, nb, flux.data_ptr(), energy.data_ptr(),
+            global_floor.data_ptr(), state.data_ptr(), init.data_ptr(), out["flux"].data_ptr(),
+            out["energy_ema"].data_ptr(), out["max_excess"].data_ptr(), out["burst_count"].data_ptr(),
+            out["flags"].data_ptr(), out["velocity"].data_ptr(), st))
+    elif nf:
         _lib.check(lib.aa_onset_gates_device(
             mags.data_ptr(), nf, nb, flux.data_ptr(), energy.data_ptr(), global_floor.data_ptr(),
             state.data_ptr(), 1 if initialized else 0, out["flux"].data_ptr(), out["energy_ema"].data_ptr(),
@@ -188,7 +218,7 @@ def onset_gates(mags, flux, energy, global_floor, state=None, stream=None):
     return out, state
 
 
-def tuner_floor(mags, global_floor, state=None, stream=None):
+def tuner_floor(mags, global_floor, state=None, stream=None, offsets=None):
     """Per-bin adaptive noise floor of the tuner (src/audio_io/stft.rs:326-367) for a CUDA float32
     magnitude spectrogram [frames, bins].  global_floor: CUDA float32 [frames]
     (= 10^(noise_floor_db/20) * bins / 2 per frame).  state: None for a fresh stream, or the
@@ -198,11 +228,17 @@ def tuner_floor(mags, global_floor, state=None, stream=None):
     lib = _lib.load()
     nf, nb = mags.shape
     initialized = state is not None
+    ns = _offsets_arg(offsets, nf) if offsets is not None else None
     if state is None:
-        state = torch.zeros((3, nb), dtype=torch.float32, device=mags.device)
+        state = torch.zeros((3, nb) if ns is None else (ns, 3, nb), dtype=torch.float32, device=mags.device)
     eff = torch.empty_like(mags)
     st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
-    if nf:
+    if nf and ns is not None:
+        init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
+        _lib.check(lib.aa_tuner_floor_batch_device(mags.data_ptr(), offsets.data_ptr(), ns, nf, nb,
+                                                   global_floor.data_ptr(), state.data_ptr(), init.data_ptr(),
+                                                   eff.data_ptr(), st))
+    elif nf:
         _lib.check(lib.aa_tuner_floor_device(mags.data_ptr(), nf, nb, global_floor.data_ptr(),
                                              state.data_ptr(), 1 if initialized else 0, eff.data_ptr(), st))
     return eff, state

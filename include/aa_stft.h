@@ -239,6 +239,29 @@ int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, i
                             int32_t n_bins, float bin_width, float min_freq, float max_freq,
                             float *out_freq_dev, float *out_score_dev, int32_t *out_count_dev, void *stream);
 
+/* ---- batches of independent streams ------------------------------------------------ */
+/* The detectors above are recurrences over the frames of ONE stream; on a GPU they pay off across
+ * streams (recordings, channels).  The batch forms take streams concatenated along the frame axis:
+ * frame_offsets_dev[n_streams + 1] (device, ascending, [0] = 0, [n_streams] = n_frames_total);
+ * stream s owns frames [off[s], off[s+1]) of every per-frame array.  State is [n_streams] x the
+ * single-stream state; initialized_dev[n_streams] (NULL = all fresh).  One wave (gates) / one lane
+ * per bin (floor) per stream; results are identical to per-stream calls.
+ * aa_onset_flux_batch_device: prev_rows_dev [n_streams][n_bins] or NULL (zeros) is the row before
+ * each stream's first frame.  aa_tuner_pitches_device needs no batch form (frames independent). */
+int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                               int64_t n_frames_total, int32_t n_bins, const float *prev_rows_dev,
+                               float *flux_dev, float *energy_dev, void *stream);
+int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                                int64_t n_frames_total, int32_t n_bins, const float *flux_dev,
+                                const float *energy_dev, const float *global_floor_dev, float *state_dev,
+                                const int32_t *initialized_dev, float *out_flux_dev, float *out_ema_dev,
+                                float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                                float *out_velocity_dev, void *stream);
+int aa_tuner_floor_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
+                                int64_t n_frames_total, int32_t n_bins, const float *global_floor_dev,
+                                float *state_dev, const int32_t *initialized_dev, float *eff_floor_dev,
+                                void *stream);
+
 /* ---- tuner: PitchTracker hysteresis (src/audio_io/stft.rs:28-117), host side ---- */
 /* Sequential over frames and tiny (<= 8 raw pitches per frame): host logic as in the reference.
  * A raw pitch within 3 % of an unmatched track updates it (EMA 0.6 / 0.4, or a snap when the

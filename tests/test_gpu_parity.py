@@ -396,6 +396,41 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
     assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32))
 
 
+def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
+    """The detectors are recurrences over one stream's frames; the batch entry points walk many
+    streams (laid end to end, frame_offsets) in parallel - one wave / one lane per bin per stream.
+    Results must be identical to calling the single-stream entry points stream by stream."""
+    from test_oracle import _burst_signal
+
+    lens = (3.0, 1.3, 2.2, 0.4)
+    for n, hop in ((256, 64), (2048, 512)):
+        plan = aa.Stft(n, hop, output="mag")
+        rows = [plan(torch_mod.from_numpy(_burst_signal(seconds=sec, seed=40 + i)).cuda()) for i, sec in enumerate(lens)]
+        counts = [r.shape[0] for r in rows]
+        mags = torch_mod.cat(rows)
+        nf, nb = mags.shape
+        offsets = torch_mod.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch_mod.int64, device="cuda")
+        gf = torch_mod.full((nf,), float(10.0 ** (-55.0 / 20.0) * nb / 2.0), device="cuda")
+        flux, energy = aa.onset_flux(mags, offsets=offsets)
+        gates, gstate = aa.onset_gates(mags, flux, energy, gf, offsets=offsets)
+        eff, fstate = aa.tuner_floor(mags, gf, offsets=offsets)
+        assert gstate.shape == (len(lens), nb + 3) and fstate.shape == (len(lens), 3, nb)
+        lo = 0
+        for i, r in enumerate(rows):
+            hi = lo + counts[i]
+            f1, e1 = aa.onset_flux(r)
+            assert torch_mod.equal(f1, flux[lo:hi]) and torch_mod.equal(e1, energy[lo:hi])
+            g1, s1 = aa.onset_gates(r, f1, e1, gf[lo:hi].contiguous())
+            for key in g1:
+                assert torch_mod.equal(g1[key], gates[key][lo:hi]), (n, i, key)
+            assert torch_mod.equal(s1.view(torch_mod.int32), gstate[i].view(torch_mod.int32))
+            t1, ts1 = aa.tuner_floor(r, gf[lo:hi].contiguous())
+            assert torch_mod.equal(t1, eff[lo:hi]) and torch_mod.equal(ts1, fstate[i])
+            lo = hi
+    with pytest.raises(aa.AaError):
+        aa.onset_flux(mags, offsets=offsets[:-1].contiguous())
+
+
 def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
     """Rest of "next" row f-1 up to the PitchTracker: multi-pitch extraction (stft.rs:443-620) on
     the tuner geometry, fed with the GPU magnitudes and effective floor.  Note counts, order and
