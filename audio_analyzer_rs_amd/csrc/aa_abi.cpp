@@ -364,29 +364,40 @@ void build_wave2048_table(const float *window, std::vector<float> *tab)
 
 // Per-lane constants of the 256-point kernel, [kWave256Rows][64] (row meaning in
 // aa_kernels.hip above stft_wave256_kernel).  q = lane & 15 is the lane within its frame.
-void build_wave256_table(const float *window, std::vector<float> *tab)
+// Per-lane constants of stft_wave_small_kernel (n_fft 256 / 512), [kWave256Rows][64]; the lane
+// map and row meaning are described above that kernel.
+void build_wave_small_table(int n_fft, const float *window, std::vector<float> *tab)
 {
     tab->assign((size_t)aa::kWave256Rows * 64, 0.0f);
     float *T = tab->data();
+    const int M = n_fft / 2, LPF = M / 8, FPW = 64 / LPF, stages = LPF == 16 ? 1 : 2, PPF = M / 2 + 1;
     for (int lane = 0; lane < 64; ++lane) {
-        // lane map before the exchange: lane = 8 q' + 2 frame + b, element column q = 8 b + q'
-        const int b = lane & 1, qp = lane >> 3, q = 8 * b + qp;
+        // before the exchange: lane = 8 q' + gamma, gamma = (frame, c); q = q' + 8 bitrev(c)
+        const int gam = lane & 7, c = gam & ((1 << stages) - 1), qp = lane >> 3;
+        const int crev = stages == 1 ? c : (((c & 1) << 1) | (c >> 1));
+        const int q = qp + 8 * crev;
         for (int j = 0; j < 8; ++j)
-            for (int c = 0; c < 2; ++c)
-                T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (16 * j + q) + c];
+            for (int cc = 0; cc < 2; ++cc)
+                T[(2 * j + cc) * 64 + lane] = 0.5f * window[2 * (LPF * j + q) + cc];
         for (int k = 1; k < 8; ++k) {
-            double a = -2.0 * kPi * (double)(q * k) / 128.0;
+            double a = -2.0 * kPi * (double)(q * k) / (double)M;
             T[(16 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
             T[(17 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
         }
-        // stage 0 (pair q', q' + 8): the odd half (b = 1) takes x[q'] - x[q' + 8], times W_16^(q')
-        T[36 * 64 + lane] = b ? -1.0f : 1.0f;
-        const double a0 = b ? -2.0 * kPi * (double)qp / 16.0 : 0.0;
-        T[30 * 64 + lane] = (float)std::cos(a0);
-        T[31 * 64 + lane] = (float)std::sin(a0);
+        // DIF stage s pairs lanes that differ in lane bit s = the q bit of weight LPF >> (s + 1);
+        // the odd half takes x[lower] - x[upper], times W_(LPF >> s)^(q mod (LPF >> (s + 1)))
+        for (int st = 0; st < stages; ++st) {
+            const int span = LPF >> st, half = span / 2;
+            const bool upper = ((lane >> st) & 1) != 0;
+            T[(36 + st) * 64 + lane] = upper ? -1.0f : 1.0f;
+            const double a = upper ? -2.0 * kPi * (double)(q % half) / (double)span : 0.0;
+            T[(30 + 2 * st) * 64 + lane] = (float)std::cos(a);
+            T[(31 + 2 * st) * 64 + lane] = (float)std::sin(a);
+        }
         for (int i = 0; i < 5; ++i) {
-            const int kk = (lane + 64 * i) % 65;
-            double th = 2.0 * kPi * (double)kk / 256.0;
+            const int p = lane + 64 * i;
+            const int kk = p < FPW * PPF ? p % PPF : 0;
+            double th = 2.0 * kPi * (double)kk / (double)n_fft;
             T[(40 + 2 * i) * 64 + lane] = (float)(-std::sin(th));
             T[(41 + 2 * i) * 64 + lane] = (float)(-std::cos(th));
         }
@@ -416,6 +427,7 @@ struct aa_stft_plan {
     bool wave2048 = false;
     bool wave1024 = false;
     bool wave256 = false;
+    bool wave512 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
     // mel / MFCC post-ops (build-defined)
@@ -696,19 +708,22 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->ws_logmel_rows = kMelSlab;
             }
         }
-        if (cfg->n_fft == 256 && cfg->hop % 4 == 0 && cfg->hop % 2 == 0) {
-            // chunk = 32 frames (8 groups of 4, two per wave); shrink in steps of 16 to fit 64 KiB
-            int fpw = 32;
-            while (fpw > 16 && aa::wave256_lds_dwords(fpw, cfg->hop) > 16384)
-                fpw -= 16;
-            if (aa::wave256_lds_dwords(fpw, cfg->hop) <= 16384) {
+        if ((cfg->n_fft == 256 || cfg->n_fft == 512) && cfg->hop % 4 == 0) {
+            // chunk = 8 groups of FPW frames (two per wave): 32 frames at 256, 16 at 512; shrink in
+            // steps of 4 groups to fit 64 KiB
+            const int fpwave = cfg->n_fft == 256 ? 4 : 2;
+            int fpw = 8 * fpwave;
+            while (fpw > 4 * fpwave && aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) > 16384)
+                fpw -= 4 * fpwave;
+            if (aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) <= 16384) {
                 std::vector<float> tab;
-                build_wave256_table(p->window_host.data(), &tab);
+                build_wave_small_table(cfg->n_fft, p->window_host.data(), &tab);
                 AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
                                  hipMemcpyHostToDevice));
                 p->frames_per_wg = fpw;
-                p->wave256 = true;
+                p->wave256 = cfg->n_fft == 256;
+                p->wave512 = cfg->n_fft == 512;
             }
         }
         if (cfg->n_fft == 2048 && cfg->hop % 64 == 0) {
@@ -821,6 +836,8 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "wave2048";
     if (p->wave256)
         return "wave256";
+    if (p->wave512)
+        return "wave512";
     return p->tabs.pow2 ? "lds_radix2" : "dft";
 }
 
@@ -852,9 +869,9 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));
-        } else if (p->wave256 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
-            AA_HIP(aa::launch_wave256(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
-                                      p->frames_per_wg, p->log_floor, st));
+        } else if ((p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+            AA_HIP(aa::launch_wave_small(p->cfg.n_fft, kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                         p->frames_per_wg, p->log_floor, st));
         } else if (p->wave2048 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave2048(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));

@@ -85,21 +85,21 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,
                            const MelSched *sched = nullptr);
 
-// ---- wave-per-4-frames 256-point kernel (onset geometry) ---------------------------
+// ---- several-frames-per-wave kernel for n_fft 256 (onset geometry) and 512 ------------------
 constexpr int kWave256Rows = 50;
-constexpr int kWave256ScratchDwords = 1152;         // per wave: exchange (1056) / four strips of 144 complex
-inline int64_t wave256_lds_dwords(int frames_per_wg, int hop)
+constexpr int kWave256ScratchDwords = 1152;         // per wave: exchange (1056) / strips / row image
+inline int64_t wave_small_lds_dwords(int n_fft, int frames_per_wg, int hop)
 {
-    const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 256;
+    const int64_t span = (int64_t)(frames_per_wg - 1) * hop + n_fft;
     return 2 * span + 4 * kWave256ScratchDwords;
 }
-inline size_t wave256_lds_bytes(int frames_per_wg, int hop)
+inline size_t wave_small_lds_bytes(int n_fft, int frames_per_wg, int hop)
 {
-    return sizeof(float) * (size_t)wave256_lds_dwords(frames_per_wg, hop);
+    return sizeof(float) * (size_t)wave_small_lds_dwords(n_fft, frames_per_wg, hop);
 }
-hipError_t launch_wave256(int out_kind, const float *x, float *out, const float *table,
-                          int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                          float log_floor, hipStream_t stream);
+hipError_t launch_wave_small(int n_fft, int out_kind, const float *x, float *out, const float *table,
+                             int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                             float log_floor, hipStream_t stream);
 
 // ---- generic kernels (any even length) ---------------------------------------
 // Frame t reads x[t*hop + i] * window[i] (window may be null).  Rows of

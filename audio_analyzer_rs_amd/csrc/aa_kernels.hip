@@ -1124,55 +1124,70 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
     }
 }
 
-// ----------------------------------------------------- wave-per-4-frames, n_fft = 256 --
-// The onset geometry of the reference (window 256, hop 64: src/analysis/onset.rs:122-123).
-// 128 complex points per frame, 16 lanes per frame, 8 points per lane, FOUR frames per wave:
-//   z[m], m = 16 j + q:  lane holds q (0..15), register j (0..7)
-//   pass A   radix-8 over j in registers, x W_128^(q k1)                  -> Y'[q][k1]
-//   stage 0  one radix-2 DIF butterfly across the lane pair (q', q' + 8) by DPP quad_perm (the
-//            pair sits in adjacent lanes, see the lane map), x W_16^(q') on the odd half:
-//            Z[k1 + 8 (2 mu + b)] = sum_q' W_8^(q' mu) u_b[q'][k1]
+// ------------------------------------- several frames per wave, n_fft = 256 and 512 --
+// 256/64 is the onset geometry of the reference (src/analysis/onset.rs:122-123); 512 shares the
+// structure.  M = n_fft/2 complex points per frame on LPF = M/8 lanes (16 / 32) with 8 points per
+// lane, so a wave transforms FPW = 64/LPF frames (4 / 2) at once:
+//   z[m], m = LPF j + q:  lane holds q, register j (0..7)
+//   pass A   radix-8 over j in registers, x W_M^(q k1)                    -> Y'[q][k1]
+//   stages   the LPF-point transform over q = q' + 8 c: log2(LPF) - 3 radix-2 DIF butterflies
+//            (1 / 2) across lane bits 0 (and 1) by DPP quad_perm - the lane map puts the partners
+//            in the same quad - each followed by its twiddle on the odd half
 //   E        registers <-> lanes through the wave's LDS scratch, the 8 x 8 transposes of
 //            stft_wave1024_kernel's E1 (same addresses, conflict free): q' <-> k1
-//   pass C   radix-8 over q' in registers -> lane l (0..15 of its frame) holds Z[l + 16 mu]
-//   split    Z of the 4 frames goes to an LDS strip (8 x ds_write_b64 per lane); 260 (k, 128-k)
-//            pairs are spread over the 64 lanes (5 per lane), each pair yields X[k] and
-//            X[128-k]; magnitudes land in a dense 4-row LDS image
-//   store    4 rows x 129 floats = 129 float4: rows 4g..4g+3 start 16-byte aligned, so the
-//            image leaves as 3 nontemporal dwordx4 stores per FOUR frames.
-// Lane map before E: lane = 8 q' + 2 frame + b (q = 8 b + q'); after E: lane = 16 frame + l.
-// (First version: all four radix-2 stages of the 16-point transform as DPP butterflies - 55 % more
-// VALU instructions per sample than the 1024 kernel, which made this kernel VALU bound.)
-// Table rows ([50][64]): 0..15 0.5*w[2(16j+q)+c] (row 2j+c), 16..29 W_128^(q k1) k1=1..7,
-// 30..31 stage-0 twiddle, 36 stage-0 sign, 40..49 -i W_256^k of the lane's five pairs
-// (k = (lane + 64 i) % 65).
-constexpr int kW256StripStride = 144;   // complex per frame in the strip (>= 129; 2*144 = 32 mod 64)
+//   pass C   radix-8 over q' in registers -> lane l (0..LPF-1 of its frame) holds Z[l + LPF mu]
+//   split    Z of the FPW frames goes to an LDS strip (8 x ds_write_b64 per lane); the (k, M-k)
+//            pairs (260 / 258) are spread over the 64 lanes, 5 per lane, each pair yields X[k]
+//            and X[M-k]; magnitudes land in a dense FPW-row LDS image
+//   store    256: 4 rows x 129 floats = 129 float4 (group starts are 16-byte aligned): 3
+//            nontemporal dwordx4 stores per FOUR frames; 512: 2 rows x 257 floats = 257 float2.
+// Lane map before E: lane = 8 q' + gamma, gamma = (frame, c) with c = the DIF output residue
+// (kappa = (LPF/8) mu + c) whose bits, reversed, are the high bits of q; after E: lane = LPF
+// frame + l.  (First 256 version: all four radix-2 stages of the 16-point transform as DPP
+// butterflies - 55 % more VALU instructions per sample than the 1024 kernel.)
+// Table rows ([50][64]): 0..15 0.5*w[2(LPF j+q)+c] (row 2j+c), 16..29 W_M^(q k1) k1=1..7,
+// 30..33 stage twiddles, 36..37 stage signs, 40..49 -i W_N^k of the lane's five pairs.
+template <int N>
+struct WaveSmall {
+    static constexpr int M = N / 2, LPF = M / 8, FPW = 64 / LPF, STAGES = (LPF == 16) ? 1 : 2;
+    static constexpr int NB = M + 1, PPF = M / 2 + 1, PAIRS = FPW * PPF;
+    static constexpr int STRIP = (N == 256) ? 144 : 264;   // complex per frame (>= NB, even; 256: 2*144 = 32 mod 64)
+    static constexpr int GROUP_STORES = (N == 256) ? 3 : 5;
+};
 
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ v2f dpp_pair(v2f old, v2f src)
 {
     return v2f{dpp_update<CTRL, BANK_MASK>(old.x, src.x), dpp_update<CTRL, BANK_MASK>(old.y, src.y)};
 }
-template <int OUT, bool WIDE>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
+template <int N, int BYTE_OFF>
+__device__ __forceinline__ v2f small_frame_read(unsigned fr)
+{
+    return lds_read_b64<BYTE_OFF * (N / 256)>(fr);
+}
+template <int N, int OUT, bool WIDE>
+__global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
     float log_floor)
 {
+    using G = WaveSmall<N>;
+    constexpr int M = G::M, LPF = G::LPF, FPW = G::FPW, NB = G::NB, PPF = G::PPF, SS = G::STRIP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // lane map before the exchange E (frame read, pass A, stage 0) and after it (split, store)
-    const int fqA = (lane >> 1) & 3, qA = 8 * (lane & 1) + (lane >> 3);
-    const int fqB = lane >> 4, lB = lane & 15;
+    // lane map before the exchange E (frame read, pass A, stages) and after it (split, store)
+    const int gam = lane & 7, cA = gam & ((1 << G::STAGES) - 1);
+    const int crev = G::STAGES == 1 ? cA : (((cA & 1) << 1) | (cA >> 1));
+    const int fqA = gam >> G::STAGES, qA = 8 * crev + (lane >> 3);
+    const int fqB = lane / LPF, lB = lane % LPF;
 
     const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
     const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
-    const int max_span = (frames_per_wg - 1) * hop + 256;
+    const int max_span = (frames_per_wg - 1) * hop + N;
     float *scrf = smem + 2 * max_span + wave * kWave256ScratchDwords;
     v2f *scr = reinterpret_cast<v2f *>(scrf);
-    constexpr int NB = 129;
     constexpr int COLS = (OUT == kComplex) ? 2 * NB : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;
@@ -1181,7 +1196,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
     const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
 
     auto stage = [&](const float *src, int nfc, int which) {
-        const int span4 = ((nfc - 1) * hop + 256) >> 2;
+        const int span4 = ((nfc - 1) * hop + N) >> 2;
         float *dst = smem + which * max_span;
         for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int qq = qb + lane;
@@ -1194,45 +1209,50 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
     if (c0 < c1)
         stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
 
-    v2f win[8], twA[8], wst0, sig0, tws[5];
+    v2f win[8], twA[8], wst[2], sig[2], tws[5];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
 #pragma unroll
     for (int k = 1; k < 8; ++k)
         twA[k] = v2f{tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]};
-    wst0 = v2f{tab[30 * 64 + lane], tab[31 * 64 + lane]};
-    sig0 = v2f{tab[36 * 64 + lane], tab[36 * 64 + lane]};
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        wst[st] = v2f{tab[(30 + 2 * st) * 64 + lane], tab[(31 + 2 * st) * 64 + lane]};
+        sig[st] = v2f{tab[(36 + st) * 64 + lane], tab[(36 + st) * 64 + lane]};
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i)
         tws[i] = v2f{tab[(40 + 2 * i) * 64 + lane], tab[(41 + 2 * i) * 64 + lane]};
 
-    // pair bookkeeping: pair p = lane + 64 i -> frame p / 65, bin k = p % 65
+    // pair bookkeeping: pair p = lane + 64 i -> frame p / PPF, bin k = p % PPF
     int pa[5], pb[5], rlo[5], rhi[5], pfr[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int p = lane + 64 * i;
-        const int fr = p / 65, k = p - 65 * fr;
-        pfr[i] = p < 260 ? fr : 4;                     // 4 = no such pair
-        pa[i] = (fr & 3) * kW256StripStride + k;
-        pb[i] = (fr & 3) * kW256StripStride + 128 - k;
-        rlo[i] = (fr & 3) * NB + k;
-        rhi[i] = (fr & 3) * NB + 128 - k;
+        const int fr = p / PPF, k = p - PPF * fr;
+        pfr[i] = p < G::PAIRS ? fr : FPW;              // FPW = no such pair
+        pa[i] = (fr % FPW) * SS + k;
+        pb[i] = (fr % FPW) * SS + M - k;
+        rlo[i] = (fr % FPW) * NB + k;
+        rhi[i] = (fr % FPW) * NB + M - k;
     }
     v2f *e_wr = scr + 66 * (lane & 7) + (lane >> 3);                        // + 8 k1   (E, as E1 at 1024)
     const v4f *e_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    v2f *strip_wr = scr + fqB * kW256StripStride + lB;                      // + 16 mu
+    v2f *strip_wr = scr + fqB * SS + lB;                                    // + LPF mu
     const unsigned smem_addr = lds_addr(smem);
+    const int groups_per_wave = frames_per_wg / (4 * FPW);   // in a full chunk
 
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
-        // counted wait as in stft_wave1024_kernel: with 32 frames per chunk every wave stored
-        // two 4-frame groups (3 stores each) in the previous (full) chunk, after issuing this
-        // chunk's DMA loads
-        if (c == c0 || frames_per_wg != 32 || OUT == kComplex || !WIDE)
+        // counted wait as in stft_wave1024_kernel: in the previous (full) chunk every wave stored
+        // two groups of FPW frames (GROUP_STORES stores each) after issuing this chunk's DMA loads
+        if (c == c0 || groups_per_wave != 2 || frames_per_wg != 8 * FPW || OUT == kComplex || !WIDE)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else
+        else if (N == 256)
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
@@ -1242,17 +1262,18 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
         }
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * qA);
 
-        for (int g = wave; 4 * g < nf; g += 4) {
-            const int t = 4 * g + fqA;                 // this lane's frame within the chunk
-            const int nvalid = nf - 4 * g < 4 ? nf - 4 * g : 4;
+        for (int g = wave; FPW * g < nf; g += 4) {
+            const int t = FPW * g + fqA;               // this lane's frame within the chunk
+            const int nvalid = nf - FPW * g < FPW ? nf - FPW * g : FPW;
             // a lane of a frame past the end reads the last valid frame instead (stays in the
             // staged span); its results are never stored
             const int tr = t < nf ? t : nf - 1;
             const unsigned fr = buf_addr + 4u * (unsigned)(tr * hop);
             v2f v[8];
-            v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<128>(fr); v[2] = lds_read_b64<256>(fr);
-            v[3] = lds_read_b64<384>(fr); v[4] = lds_read_b64<512>(fr); v[5] = lds_read_b64<640>(fr);
-            v[6] = lds_read_b64<768>(fr); v[7] = lds_read_b64<896>(fr);
+            v[0] = small_frame_read<N, 0>(fr); v[1] = small_frame_read<N, 128>(fr);
+            v[2] = small_frame_read<N, 256>(fr); v[3] = small_frame_read<N, 384>(fr);
+            v[4] = small_frame_read<N, 512>(fr); v[5] = small_frame_read<N, 640>(fr);
+            v[6] = small_frame_read<N, 768>(fr); v[7] = small_frame_read<N, 896>(fr);
             lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -1262,24 +1283,32 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
             for (int k = 1; k < 8; ++k)
                 v[k] = pk_cmul(v[k], twA[k]);
 
-            // ---- stage 0: radix-2 across the lane pair (b = 0 / 1), twiddle on the odd half ----
+            // ---- radix-2 DIF stages across lane bits 0 (and 1): partner in the same quad ----
             hazard_fence(v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);        // quad_perm [1,0,3,2]: lane ^ 1
-                v[k] = pk_cmul(v[k] * sig0 + p, wst0);
+                v[k] = pk_cmul(v[k] * sig[0] + p, wst[0]);
+            }
+            if (G::STAGES == 2) {
+                hazard_fence(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v2f p = dpp_pair<0x4E, 0xF>(v[k], v[k]);    // quad_perm [2,3,0,1]: lane ^ 2
+                    v[k] = pk_cmul(v[k] * sig[1] + p, wst[1]);
+                }
             }
             // ---- E: q' <-> k1 through LDS (addresses of stft_wave1024_kernel's E1) ----
             fft512_exchange1(v, e_wr, e_rd);
-            // ---- pass C: lane l of its frame ends with Z[l + 16 mu] in register mu ----
+            // ---- pass C: lane l of its frame ends with Z[l + LPF mu] in register mu ----
             pk_dft8(v);
 
-            // ---- strip: Z of the four frames, Z[128] := Z[0] ----
+            // ---- strip: Z of the FPW frames, Z[M] := Z[0] ----
 #pragma unroll
             for (int mu = 0; mu < 8; ++mu)
-                strip_wr[16 * mu] = v[mu];
+                strip_wr[LPF * mu] = v[mu];
             if (lB == 0)
-                scr[fqB * kW256StripStride + 128] = v[0];
+                scr[fqB * SS + M] = v[0];
             __builtin_amdgcn_wave_barrier();
             v2f za[5], zb[5];
 #pragma unroll
@@ -1288,12 +1317,12 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
                 zb[i] = scr[pb[i]];
             }
             __builtin_amdgcn_wave_barrier();
-            float *grp = out_chunk + (4 * g) * COLS;   // first row of the group
+            float *grp = out_chunk + (FPW * g) * COLS;   // first row of the group
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 v2f e = pk_add_conj(za[i], zb[i]), o = pk_sub_conj(za[i], zb[i]);
                 v2f tt = pk_cmul(o, tws[i]);
-                v2f xk = e + tt, xm = e - tt;          // X[128-k] = conj(xm)
+                v2f xk = e + tt, xm = e - tt;          // X[M-k] = conj(xm)
                 const bool live = pfr[i] < nvalid;
                 if (OUT == kComplex) {
                     if (live) {
@@ -1303,7 +1332,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
                 } else {
                     const float mk = bin_value<OUT>(xk.x, xk.y, log_floor);
                     const float mm = bin_value<OUT>(xm.x, xm.y, log_floor);
-                    if (pfr[i] < 4) {
+                    if (pfr[i] < FPW) {
                         scrf[rlo[i]] = mk;
                         scrf[rhi[i]] = mm;
                     }
@@ -1311,7 +1340,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
             }
             if (OUT != kComplex) {
                 __builtin_amdgcn_wave_barrier();
-                if (WIDE && nvalid == 4) {
+                if (WIDE && nvalid == FPW && N == 256) {
                     // 516 floats = 129 float4, group start 16-byte aligned
                     v4f b0 = *reinterpret_cast<const v4f *>(scrf + 4 * lane);
                     v4f b1 = *reinterpret_cast<const v4f *>(scrf + 256 + 4 * lane);
@@ -1320,6 +1349,16 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave256_kernel(
                     __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(grp + 256 + 4 * lane));
                     if (lane == 0)
                         __builtin_nontemporal_store(b2, reinterpret_cast<v4f *>(grp + 512));
+                } else if (WIDE && nvalid == FPW) {
+                    // 514 floats = 257 float2, group start 8-byte aligned
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v2f b = *reinterpret_cast<const v2f *>(scrf + 128 * u + 2 * lane);
+                        __builtin_nontemporal_store(b, reinterpret_cast<v2f *>(grp + 128 * u + 2 * lane));
+                    }
+                    v2f bt = *reinterpret_cast<const v2f *>(scrf + 512);
+                    if (lane == 0)
+                        __builtin_nontemporal_store(bt, reinterpret_cast<v2f *>(grp + 512));
                 } else {
                     const int nfl = NB * nvalid;
 #pragma unroll
@@ -1664,48 +1703,60 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
     }
 }
 
-template <int K>
-static hipError_t launch_wave256_kind(bool wide, const float *x, float *out, const float *table,
+template <int N, int K>
+static hipError_t launch_wave_small_kind(bool wide, const float *x, float *out, const float *table,
                                       int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                       float log_floor, hipStream_t stream)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave256_lds_bytes(frames_per_wg, hop);
+    const size_t lds = wave_small_lds_bytes(N, frames_per_wg, hop);
     static int cached_grid = 0;
     static size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
-        cached_grid = persistent_grid(stft_wave256_kernel<K, true>, lds);
+        cached_grid = persistent_grid(stft_wave_small_kernel<N, K, true>, lds);
         cached_lds = lds;
     }
     const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
     if (wide)
-        hipLaunchKernelGGL((stft_wave256_kernel<K, true>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave_small_kernel<N, K, true>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
     else
-        hipLaunchKernelGGL((stft_wave256_kernel<K, false>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave_small_kernel<N, K, false>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor);
     return hipGetLastError();
 }
 
-hipError_t launch_wave256(int out_kind, const float *x, float *out, const float *table,
-                          int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                          float log_floor, hipStream_t stream)
+template <int N>
+static hipError_t launch_wave_small_n(int out_kind, const float *x, float *out, const float *table,
+                                      int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                                      float log_floor, hipStream_t stream)
 {
     if (n_frames <= 0)
         return hipSuccess;
     const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave256_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave_small_kind<N, kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kMag:
-        return launch_wave256_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave_small_kind<N, kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kPower:
-        return launch_wave256_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave_small_kind<N, kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     case kLogPower:
-        return launch_wave256_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+        return launch_wave_small_kind<N, kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     default:
         return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_wave_small(int n_fft, int out_kind, const float *x, float *out, const float *table,
+                             int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
+                             float log_floor, hipStream_t stream)
+{
+    if (n_fft == 256)
+        return launch_wave_small_n<256>(out_kind, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    if (n_fft == 512)
+        return launch_wave_small_n<512>(out_kind, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float *out,

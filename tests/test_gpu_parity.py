@@ -58,6 +58,8 @@ def test_kernel_selection(aa):
     assert aa.Stft(2048, 500).kernel == "lds_radix2"
     assert aa.Stft(256, 64).kernel == "wave256"             # onset geometry (onset.rs:122-123)
     assert aa.Stft(256, 63).kernel == "lds_radix2"
+    assert aa.Stft(512, 128).kernel == "wave512"
+    assert aa.Stft(512, 126).kernel == "lds_radix2"
     assert aa.Stft(1000, 250).kernel == "dft"
 
 
@@ -130,32 +132,34 @@ def test_wave2048_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
 
 @pytest.mark.parametrize("n_frames", [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4099])
 @pytest.mark.parametrize("output", ["mag", "complex"])
-def test_wave256_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
-    """The onset geometry (256 / 64, src/analysis/onset.rs:122-123): four frames per wave."""
-    n, hop = 256, 64
-    rng = np.random.default_rng(300 + n_frames)
+@pytest.mark.parametrize("n", [256, 512])
+def test_wave256_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output, n):
+    """The onset geometry (256 / 64, src/analysis/onset.rs:122-123): four frames per wave; the same
+    kernel structure at 512 / 128 (two frames per wave)."""
+    hop = n // 4
+    rng = np.random.default_rng(300 + n_frames + n)
     L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
     x = (0.5 * rng.standard_normal(L)).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == "wave256"
+    assert plan.kernel == f"wave{n}"
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
     tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
     tru = tru if output == "complex" else np.abs(tru)
-    assert got.shape == ref.shape == (n_frames, 129)
+    assert got.shape == ref.shape == (n_frames, n // 2 + 1)
     assert nerr(got, ref.astype(tru.dtype)).max() < TOL_VS_ORACLE
     assert nerr(got, tru).max() < TOL_VS_TRUTH
 
 
 @pytest.mark.parametrize("hop", [4, 32, 64, 128, 256, 300])
-def test_wave256_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
-    n = 256
+@pytest.mark.parametrize("n", [256, 512])
+def test_wave256_hops_and_outputs(aa, oracle_mod, torch_mod, hop, n):
     x = aa.signals.synth_corpus(555, n + 200 * hop + 1)
     w = oracle_mod.hann_window(n)
     P = np.abs(oracle_mod.truth.stft_complex(x, n, hop, w)) ** 2
     xd = torch_mod.from_numpy(x).cuda()
     plan = aa.Stft(n, hop, output="power")
-    assert plan.kernel == "wave256"
+    assert plan.kernel == f"wave{n}"
     assert nerr(plan(xd).cpu().numpy(), P).max() < 2 * TOL_VS_TRUTH
     part = aa.Stft(n, hop, output="mag").execute_device(xd, 5, 131).cpu().numpy()
     assert nerr(part, np.sqrt(P[5:131])).max() < TOL_VS_TRUTH
@@ -197,7 +201,7 @@ def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
 
 
 # -------------------------------------------------------------------- generic paths --
-@pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 128),
+@pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 126),
                                    (1024, 100), (2048, 500), (4096, 1024), (8192, 4096)])
 @pytest.mark.parametrize("output", ["mag", "complex"])
 def test_lds_radix2_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
