@@ -11,7 +11,7 @@ from .fft import FftProcessor, hann_window  # noqa: F401
 from .stft import (PitchTracker, Stft, StftStream, downmix, onset_flux, onset_gates, pin, tuner_floor,  # noqa: F401
                    tuner_pitches, unpin)
 from .sharding import ShardPlan, gather_rows, scatter_samples, shard_frames, shard_samples  # noqa: F401
-from . import signals  # noqa: F401
+from . import signals, wav  # noqa: F401
 
 
 def load_library():

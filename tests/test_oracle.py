@@ -246,3 +246,38 @@ def test_oracle_header_says_parity_unpinned():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "oracle", "stft_oracle.c")).read()
     assert "PARITY UNPINNED" in src and "TEST INFRASTRUCTURE ONLY" in src
+
+
+def test_wav_format_matches_recorder_semantics(tmp_path):
+    """ "next" row f-4 (input half): the recorder's WAV format (recorder.rs:60-85) and the decoder's
+    scaling - integer work, exact."""
+    import audio_analyzer_rs_amd as aa
+
+    x = np.array([0.0, 1.0, -1.0, 2.0, -3.0, 0.5, -0.5, 1e-6, -1e-6, 0.999985, np.nan, 3.0517578e-05],
+                 dtype=np.float32)
+    q = aa.wav.encode_pcm16(x)
+    assert q.dtype == np.int16
+    assert q.tolist() == [0, 32767, -32767, 32767, -32767, 16383, -16383, 0, 0, 32766, -32767, 0]
+    assert np.array_equal(aa.wav.decode_pcm16(q), q.astype(np.float32) / np.float32(32768.0))
+    sig = aa.signals.synth_corpus(3, 48000)
+    path = tmp_path / "rec.wav"
+    aa.wav.write_wav(path, sig, 48000)
+    back, sr = aa.wav.read_wav(path)
+    assert sr == 48000 and back.dtype == np.float32 and back.shape == sig.shape
+    assert np.array_equal(back, aa.signals.pcm16_roundtrip(sig))
+    assert np.max(np.abs(back - sig)) <= 2.0 / 32768.0           # truncation + the 32767 / 32768 gain
+    # stereo files come back as [frames, channels]
+    import wave
+
+    st = np.stack([aa.wav.encode_pcm16(sig[:1000]), aa.wav.encode_pcm16(-sig[:1000])], axis=1)
+    with wave.open(str(tmp_path / "st.wav"), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(44100)
+        w.writeframes(st.astype("<i2").tobytes())
+    y, sr2 = aa.wav.read_wav(tmp_path / "st.wav")
+    assert sr2 == 44100 and y.shape == (1000, 2) and np.array_equal(y[:, 0], aa.wav.decode_pcm16(st[:, 0]))
+    # the onset JSON the front end polls (lib.rs:326-338)
+    assert aa.wav.onsets_json([1.5, 2.25], [-96, 12], [0.5, 1.0]) == (
+        '[{"beat_position":1.500000,"raw_sample_offset":-96,"velocity":0.5000},'
+        '{"beat_position":2.250000,"raw_sample_offset":12,"velocity":1.0000}]')
