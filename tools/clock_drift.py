@@ -13,7 +13,7 @@ st = torch.cuda.current_stream().cuda_stream
 torch.cuda.synchronize()
 t_start = time.perf_counter()
 evs = []
-for w in range(60):
+for w in range(int(os.environ.get("AA_DRIFT_WINDOWS", "60"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(200):
