@@ -200,6 +200,36 @@ def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
     assert nerr(mis, ref.astype(np.float64)).max() < TOL_VS_ORACLE
 
 
+def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
+    """60 seeded random (n_fft, hop, output, length, frame range) combinations across every kernel
+    (wave1024 / 2048 / 256 / 512, generic, dft) against the float64 truth: ragged last chunks,
+    sub-ranges, odd hops, unaligned range starts."""
+    rng = np.random.default_rng(20260101)
+    seen = set()
+    for case in range(60):
+        n = int(rng.choice([256, 512, 1024, 2048, 64, 4096, 1000]))
+        hop = int(rng.choice([n // 4, n // 2, n // 8, n, 64, 192, 100, 37, int(rng.integers(1, n + 50))]))
+        hop = max(hop, 1)
+        output = str(rng.choice(["mag", "power", "complex"]))
+        n_frames = int(rng.integers(1, 400))
+        L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
+        if L > 2_000_000:
+            continue
+        x = (0.3 * rng.standard_normal(L)).astype(np.float32)
+        plan = aa.Stft(n, hop, output=output)
+        seen.add(plan.kernel)
+        f0 = int(rng.integers(0, n_frames))
+        f1 = int(rng.integers(f0, n_frames + 1))
+        got = plan.execute_device(torch_mod.from_numpy(x).cuda(), f0, f1).cpu().numpy()
+        tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))[f0:f1]
+        ref = tru if output == "complex" else (np.abs(tru) if output == "mag" else np.abs(tru) ** 2)
+        assert got.shape == ref.shape, (case, n, hop, output, f0, f1)
+        if f1 > f0:
+            tol = TOL_VS_TRUTH * (2 if output == "power" else 1)
+            assert nerr(got, ref).max() < tol, (case, n, hop, output, f0, f1, plan.kernel)
+    assert {"wave1024", "wave2048", "wave256", "wave512", "lds_radix2", "dft"} <= seen
+
+
 # -------------------------------------------------------------------- generic paths --
 @pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 126),
                                    (1024, 100), (2048, 500), (4096, 1024), (8192, 4096)])
