@@ -362,8 +362,6 @@ void build_wave2048_table(const float *window, std::vector<float> *tab)
     }
 }
 
-// Per-lane constants of the 256-point kernel, [kWave256Rows][64] (row meaning in
-// aa_kernels.hip above stft_wave256_kernel).  q = lane & 15 is the lane within its frame.
 // Per-lane constants of stft_wave_small_kernel (n_fft 256 / 512), [kWave256Rows][64]; the lane
 // map and row meaning are described above that kernel.
 void build_wave_small_table(int n_fft, const float *window, std::vector<float> *tab)
