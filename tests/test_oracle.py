@@ -281,3 +281,32 @@ def test_wav_format_matches_recorder_semantics(tmp_path):
     assert aa.wav.onsets_json([1.5, 2.25], [-96, 12], [0.5, 1.0]) == (
         '[{"beat_position":1.500000,"raw_sample_offset":-96,"velocity":0.5000},'
         '{"beat_position":2.250000,"raw_sample_offset":12,"velocity":1.0000}]')
+
+
+def test_detector_restatements_vs_golden(oracle_mod):
+    """tests/golden/detectors_golden.npz (make_detector_golden.py) pins the "next"-row restatements:
+    integer / flag outputs exactly, float recurrences exactly (plain f32 arithmetic), the
+    logf-based pitch values to 1e-6 (libm may differ by an ulp between builds)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detectors_golden.npz"))
+    mags = oracle_mod.stft(g["onset_x"], 256, 64, kind="mag")
+    flux, energy = oracle_mod.onset_flux(mags)
+    assert np.allclose(flux, g["onset_flux"], rtol=2e-6, atol=1e-6) and np.allclose(energy, g["onset_energy"], rtol=2e-6)
+    gates, state, _ = oracle_mod.onset_gates(mags, g["onset_flux"], g["onset_energy"],
+                                            np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0))
+    for k in ("burst_count", "flags"):
+        assert np.array_equal(gates[k], g["gate_" + k]), k
+    for k in ("flux", "energy_ema", "max_excess", "velocity"):
+        assert np.allclose(gates[k], g["gate_" + k], rtol=2e-6, atol=1e-7), k
+    assert int((g["gate_flags"] & 16 > 0).sum()) == 3
+    tm = oracle_mod.stft(g["tuner_x"], 2048, 512, kind="mag")
+    nb = tm.shape[1]
+    eff, tstate, _ = oracle_mod.tuner_floor(tm, np.float32(10.0 ** (-60.0 / 20.0) * nb / 2.0))
+    assert np.allclose(eff[[0, 1, 10, eff.shape[0] - 1]], g["tuner_eff_rows"], rtol=2e-6)
+    assert np.allclose(eff.astype(np.float64).sum(axis=1), g["tuner_eff_sum"], rtol=1e-6)
+    freq, score, count = oracle_mod.extract_pitches(tm, eff, 48000.0 / 2048.0)
+    assert np.array_equal(count, g["tuner_count"])
+    assert np.allclose(freq, g["tuner_freq"], rtol=1e-6) and np.allclose(score, g["tuner_score"], rtol=1e-6)
+    sf, ss, sc = oracle_mod.pitch_tracker(g["tuner_freq"], g["tuner_score"], g["tuner_count"])
+    assert np.array_equal(sc, g["tracker_count"]) and np.array_equal(sf[:, :8], g["tracker_freq"])
