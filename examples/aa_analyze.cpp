@@ -1,0 +1,218 @@
+// Offline analyser for a recorded practice session, written against the C ABI only
+// (include/aa_stft.h + the HIP runtime for device buffers): what a compiled host — the reference is
+// a Rust crate — does with libaa_stft.so.  Reads the recorder's WAV (16-bit PCM mono,
+// src/audio_io/recorder.rs:60-85), runs the tuner chain (2048/512 STFT -> noise floor -> pitches ->
+// PitchTracker, src/audio_io/stft.rs) and the onset chain (256/64 STFT -> flux -> gates,
+// src/analysis/onset.rs) on the GPU and prints JSON:
+//   {"sample_rate":..,"frames":..,"onsets":[{"beat_position":..,"raw_sample_offset":..,"velocity":..},..],
+//    "notes":[{"frame":..,"pitches":[[freq,score],..]},..]}
+// Usage: aa_analyze <file.wav> [bpm=120] [noise_floor_db=-60] [note_stride=50]
+// Build: make -C audio_analyzer_rs_amd/csrc examples
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aa_stft.h"
+
+#define CHECK_AA(call)                                                                      \
+    do {                                                                                    \
+        int rc_ = (call);                                                                   \
+        if (rc_ != AA_OK) {                                                                 \
+            std::fprintf(stderr, "%s failed: %d (%s)\n", #call, rc_, aa_last_error());      \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)
+#define CHECK_HIP(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            std::fprintf(stderr, "%s failed: %s\n", #call, hipGetErrorString(e_));          \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+// Minimal RIFF/WAVE reader: 16-bit PCM, first channel pair averaged like the capture path
+// (audio_io/mod.rs:784-794); samples decoded as i16 / 32768.
+static bool read_wav(const char *path, std::vector<float> *out, int *sample_rate)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f)
+        return false;
+    std::vector<unsigned char> buf;
+    unsigned char tmp[65536];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0)
+        buf.insert(buf.end(), tmp, tmp + n);
+    std::fclose(f);
+    if (buf.size() < 44 || std::memcmp(buf.data(), "RIFF", 4) != 0 || std::memcmp(buf.data() + 8, "WAVE", 4) != 0)
+        return false;
+    auto u16 = [&](size_t o) { return (unsigned)buf[o] | ((unsigned)buf[o + 1] << 8); };
+    auto u32 = [&](size_t o) { return (uint32_t)u16(o) | ((uint32_t)u16(o + 2) << 16); };
+    int channels = 0, bits = 0, fmt = 0;
+    size_t pos = 12;
+    while (pos + 8 <= buf.size()) {
+        const uint32_t len = u32(pos + 4);
+        if (std::memcmp(buf.data() + pos, "fmt ", 4) == 0 && pos + 24 <= buf.size()) {
+            fmt = (int)u16(pos + 8);
+            channels = (int)u16(pos + 10);
+            *sample_rate = (int)u32(pos + 12);
+            bits = (int)u16(pos + 22);
+        } else if (std::memcmp(buf.data() + pos, "data", 4) == 0) {
+            if (fmt != 1 || bits != 16 || channels < 1)
+                return false;
+            const size_t avail = std::min<size_t>(len, buf.size() - pos - 8);
+            const size_t frames = avail / (2 * (size_t)channels);
+            const int used = channels < 2 ? 1 : 2;
+            out->resize(frames);
+            for (size_t i = 0; i < frames; ++i) {
+                float acc = 0.0f;
+                for (int c = 0; c < used; ++c) {
+                    const size_t o = pos + 8 + 2 * (i * (size_t)channels + (size_t)c);
+                    acc += (float)(int16_t)u16(o) / 32768.0f;
+                }
+                (*out)[i] = acc / (float)used;
+            }
+            return true;
+        }
+        pos += 8 + len + (len & 1);
+    }
+    return false;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s file.wav [bpm=120] [noise_floor_db=-60] [note_stride=50]\n", argv[0]);
+        return 1;
+    }
+    const double bpm = argc > 2 ? std::atof(argv[2]) : 120.0;
+    const float noise_floor_db = argc > 3 ? (float)std::atof(argv[3]) : -60.0f;
+    const int note_stride = argc > 4 ? std::atoi(argv[4]) : 50;
+    std::vector<float> x;
+    int sr = 0;
+    if (!read_wav(argv[1], &x, &sr)) {
+        std::fprintf(stderr, "%s: not a 16-bit PCM WAV file\n", argv[1]);
+        return 1;
+    }
+    const int64_t n = (int64_t)x.size();
+    float *d_x = nullptr;
+    CHECK_HIP(hipMalloc(&d_x, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
+    CHECK_HIP(hipMemcpy(d_x, x.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+
+    // ---- tuner chain: 2048 / 512 (stft.rs:169-170) ----
+    aa_stft_config cfg{};
+    cfg.n_fft = 2048;
+    cfg.hop = 512;
+    cfg.window = AA_WINDOW_HANN_PERIODIC;
+    cfg.output = AA_OUT_MAG;
+    cfg.sample_rate = sr;
+    aa_stft_plan *tuner = nullptr;
+    CHECK_AA(aa_stft_plan_create(&cfg, nullptr, &tuner));
+    const int64_t tf = aa_stft_num_frames(tuner, n);
+    const int tb = aa_stft_out_cols(tuner);
+    std::vector<float> nf_freq((size_t)tf * 8), nf_score((size_t)tf * 8);
+    std::vector<int32_t> nf_count((size_t)tf);
+    std::vector<float> st_freq((size_t)tf * AA_PITCH_TRACKS_MAX), st_score((size_t)tf * AA_PITCH_TRACKS_MAX);
+    std::vector<int32_t> st_count((size_t)tf);
+    if (tf > 0) {
+        float *d_mag, *d_eff, *d_gf, *d_state, *d_freq, *d_score;
+        int32_t *d_count;
+        CHECK_HIP(hipMalloc(&d_mag, sizeof(float) * (size_t)tf * tb));
+        CHECK_HIP(hipMalloc(&d_eff, sizeof(float) * (size_t)tf * tb));
+        CHECK_HIP(hipMalloc(&d_gf, sizeof(float) * (size_t)tf));
+        CHECK_HIP(hipMalloc(&d_state, sizeof(float) * 3 * (size_t)tb));
+        CHECK_HIP(hipMalloc(&d_freq, sizeof(float) * (size_t)tf * 8));
+        CHECK_HIP(hipMalloc(&d_score, sizeof(float) * (size_t)tf * 8));
+        CHECK_HIP(hipMalloc(&d_count, sizeof(int32_t) * (size_t)tf));
+        // global_floor = 10^(noise_floor_db / 20) * half_size / 2 (stft.rs:322-324), constant here
+        std::vector<float> gf((size_t)tf, std::pow(10.0f, noise_floor_db / 20.0f) * (float)tb / 2.0f);
+        CHECK_HIP(hipMemcpy(d_gf, gf.data(), sizeof(float) * (size_t)tf, hipMemcpyHostToDevice));
+        CHECK_AA(aa_stft_execute_device(tuner, d_x, n, 0, tf, d_mag, nullptr));
+        CHECK_AA(aa_tuner_floor_device(d_mag, tf, tb, d_gf, d_state, 0, d_eff, nullptr));
+        CHECK_AA(aa_tuner_pitches_device(d_mag, d_eff, tf, tb, (float)sr / 2048.0f, 24.0f, 10000.0f, d_freq,
+                                         d_score, d_count, nullptr));
+        CHECK_HIP(hipMemcpy(nf_freq.data(), d_freq, sizeof(float) * (size_t)tf * 8, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(nf_score.data(), d_score, sizeof(float) * (size_t)tf * 8, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(nf_count.data(), d_count, sizeof(int32_t) * (size_t)tf, hipMemcpyDeviceToHost));
+        aa_pitch_tracker *trk = nullptr;
+        CHECK_AA(aa_pitch_tracker_create(&trk));
+        CHECK_AA(aa_pitch_tracker_process(trk, nf_freq.data(), nf_score.data(), nf_count.data(), nullptr, tf,
+                                          st_freq.data(), st_score.data(), st_count.data()));
+        aa_pitch_tracker_destroy(trk);
+        for (void *p : {(void *)d_mag, (void *)d_eff, (void *)d_gf, (void *)d_state, (void *)d_freq, (void *)d_score,
+                        (void *)d_count})
+            (void)hipFree(p);
+    }
+    aa_stft_plan_destroy(tuner);
+
+    // ---- onset chain: 256 / 64 (onset.rs:122-123) ----
+    cfg.n_fft = 256;
+    cfg.hop = 64;
+    aa_stft_plan *onset = nullptr;
+    CHECK_AA(aa_stft_plan_create(&cfg, nullptr, &onset));
+    const int64_t of = aa_stft_num_frames(onset, n);
+    const int ob = aa_stft_out_cols(onset);
+    std::vector<uint8_t> flags((size_t)of);
+    std::vector<float> velocity((size_t)of);
+    if (of > 0) {
+        float *d_mag, *d_flux, *d_energy, *d_gf, *d_state, *d_oflux, *d_ema, *d_exc, *d_vel;
+        int32_t *d_cnt;
+        uint8_t *d_flags;
+        CHECK_HIP(hipMalloc(&d_mag, sizeof(float) * (size_t)of * ob));
+        for (float **p : {&d_flux, &d_energy, &d_gf, &d_oflux, &d_ema, &d_exc, &d_vel})
+            CHECK_HIP(hipMalloc(p, sizeof(float) * (size_t)of));
+        CHECK_HIP(hipMalloc(&d_state, sizeof(float) * (size_t)(ob + 3)));
+        CHECK_HIP(hipMalloc(&d_cnt, sizeof(int32_t) * (size_t)of));
+        CHECK_HIP(hipMalloc(&d_flags, (size_t)of));
+        std::vector<float> gf((size_t)of, std::pow(10.0f, noise_floor_db / 20.0f) * (float)ob / 2.0f);
+        CHECK_HIP(hipMemcpy(d_gf, gf.data(), sizeof(float) * (size_t)of, hipMemcpyHostToDevice));
+        CHECK_AA(aa_stft_execute_device(onset, d_x, n, 0, of, d_mag, nullptr));
+        CHECK_AA(aa_onset_flux_device(d_mag, of, ob, nullptr, d_flux, d_energy, nullptr));
+        CHECK_AA(aa_onset_gates_device(d_mag, of, ob, d_flux, d_energy, d_gf, d_state, 0, d_oflux, d_ema, d_exc,
+                                       d_cnt, d_flags, d_vel, nullptr));
+        CHECK_HIP(hipMemcpy(flags.data(), d_flags, (size_t)of, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(velocity.data(), d_vel, sizeof(float) * (size_t)of, hipMemcpyDeviceToHost));
+        for (void *p : {(void *)d_mag, (void *)d_flux, (void *)d_energy, (void *)d_gf, (void *)d_state,
+                        (void *)d_oflux, (void *)d_ema, (void *)d_exc, (void *)d_vel, (void *)d_cnt, (void *)d_flags})
+            (void)hipFree(p);
+    }
+    aa_stft_plan_destroy(onset);
+    (void)hipFree(d_x);
+
+    // ---- JSON ----
+    std::string js = "{\"sample_rate\":" + std::to_string(sr) + ",\"frames\":" + std::to_string(tf) + ",\"onsets\":[";
+    bool first = true;
+    char item[160];
+    for (int64_t t = 0; t < of; ++t) {
+        if (!(flags[(size_t)t] & 16))
+            continue;
+        // window centre of frame t; the format of OnsetDetection::poll_onsets (lib.rs:326-338)
+        const int64_t centre = t * 64 + 128;
+        std::snprintf(item, sizeof item, "%s{\"beat_position\":%.6f,\"raw_sample_offset\":%lld,\"velocity\":%.4f}",
+                      first ? "" : ",", (double)centre / sr * bpm / 60.0, (long long)centre, velocity[(size_t)t]);
+        js += item;
+        first = false;
+    }
+    js += "],\"notes\":[";
+    first = true;
+    for (int64_t t = 0; t < tf; t += note_stride > 0 ? note_stride : 1) {
+        std::snprintf(item, sizeof item, "%s{\"frame\":%lld,\"pitches\":[", first ? "" : ",", (long long)t);
+        js += item;
+        for (int i = 0; i < st_count[(size_t)t]; ++i) {
+            std::snprintf(item, sizeof item, "%s[%.3f,%.4f]", i ? "," : "",
+                          st_freq[(size_t)t * AA_PITCH_TRACKS_MAX + i], st_score[(size_t)t * AA_PITCH_TRACKS_MAX + i]);
+            js += item;
+        }
+        js += "]}";
+        first = false;
+    }
+    js += "]}";
+    std::puts(js.c_str());
+    return 0;
+}

@@ -465,6 +465,55 @@ def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
         aa.onset_flux(mags, offsets=offsets[:-1].contiguous())
 
 
+def test_cpp_example_host_program(aa, torch_mod, tmp_path):
+    """examples/aa_analyze.cpp drives the whole offline chain from compiled code through the C
+    ABI alone (WAV in, JSON out); its output must agree with the same chain run through the
+    Python mirror."""
+    import json
+    import os
+    import subprocess
+
+    from test_oracle import _burst_signal, _chord_signal
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "aa_analyze")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "audio_analyzer_rs_amd", "csrc"), "-s", "examples"])
+    sr = 48000
+    x = (0.6 * _chord_signal(seconds=2.0, seed=5) + _burst_signal(seconds=2.0, seed=6)).astype(np.float32)
+    wav = tmp_path / "session.wav"
+    aa.wav.write_wav(wav, x, sr)
+    res = json.loads(subprocess.check_output([exe, str(wav), "90", "-60", "10"], timeout=120).decode())
+    y, _ = aa.wav.read_wav(wav)
+    yd = torch_mod.from_numpy(y).cuda()
+    # onsets
+    om = aa.Stft(256, 64, output="mag")(yd)
+    flux, energy = aa.onset_flux(om)
+    gf = torch_mod.full((om.shape[0],), float(np.float32(10.0) ** np.float32(-60.0 / 20.0) * np.float32(129) / 2), device="cuda")
+    gates, _ = aa.onset_gates(om, flux, energy, gf)
+    fired = np.nonzero((gates["flags"].cpu().numpy() & 16) > 0)[0]
+    assert len(res["onsets"]) == len(fired) >= 2
+    for o, t in zip(res["onsets"], fired):
+        assert o["raw_sample_offset"] == t * 64 + 128
+        assert abs(o["beat_position"] - (t * 64 + 128) / sr * 90 / 60) < 1e-5
+        assert abs(o["velocity"] - float(gates["velocity"][t])) < 1e-4
+    # notes
+    tm = aa.Stft(2048, 512, output="mag")(yd)
+    nb = tm.shape[1]
+    tgf = torch_mod.full((tm.shape[0],), float(np.float32(10.0) ** np.float32(-60.0 / 20.0) * np.float32(nb) / 2), device="cuda")
+    eff, _ = aa.tuner_floor(tm, tgf)
+    fr, sc, cnt = aa.tuner_pitches(tm, eff, sr / 2048)
+    sf, ss, scnt = aa.PitchTracker().process(fr.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy())
+    assert res["sample_rate"] == sr and res["frames"] == tm.shape[0]
+    assert [n["frame"] for n in res["notes"]] == list(range(0, tm.shape[0], 10))
+    for n in res["notes"]:
+        t = n["frame"]
+        assert len(n["pitches"]) == scnt[t]
+        for (f, s_), rf, rs in zip(n["pitches"], sf[t], ss[t]):
+            assert abs(f - rf) < 2e-3 and abs(s_ - rs) < 2e-4
+    assert max(len(n["pitches"]) for n in res["notes"]) >= 2
+
+
 def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
     """Rest of "next" row f-1 up to the PitchTracker: multi-pitch extraction (stft.rs:443-620) on
     the tuner geometry, fed with the GPU magnitudes and effective floor.  Note counts, order and
