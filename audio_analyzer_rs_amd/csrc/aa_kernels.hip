@@ -276,17 +276,18 @@ __device__ __forceinline__ void mel_lds_wait(v2f &a, v2f &b)
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
 }
-// four bins of one filter slice: weights from the two triangle edges, accumulate
-__device__ __forceinline__ void mel_step4(float &acc, float &fi, v2f pa, v2f pb, float U0, float DU, float D0, float DD)
+// four bins of one filter slice: weights from the two triangle edges, accumulate.  The two edge
+// lines advance as one packed pair (u, d) += (DU, -DD) and the products accumulate two bins per
+// v_pk_fma_f32: the wave is issue bound here, packed math halves the slots of those parts.
+__device__ __forceinline__ void mel_step4(v2f &acc2, float &fi, v2f pa, v2f pb, v2f ud0, v2f dud)
 {
-    const float u0 = fmaf(fi, DU, U0), d0 = fmaf(-fi, DD, D0);
-    const float u1 = u0 + DU, d1 = d0 - DD;
-    const float u2 = u1 + DU, d2 = d1 - DD;
-    const float u3 = u2 + DU, d3 = d2 - DD;
-    acc = fmaf(__builtin_amdgcn_fmed3f(u0, d0, 0.0f), pa.x, acc);
-    acc = fmaf(__builtin_amdgcn_fmed3f(u1, d1, 0.0f), pa.y, acc);
-    acc = fmaf(__builtin_amdgcn_fmed3f(u2, d2, 0.0f), pb.x, acc);
-    acc = fmaf(__builtin_amdgcn_fmed3f(u3, d3, 0.0f), pb.y, acc);
+    const v2f f2 = {fi, fi};
+    const v2f e0 = f2 * dud + ud0;
+    const v2f e1 = e0 + dud, e2 = e1 + dud, e3 = e2 + dud;
+    const v2f w01 = {__builtin_amdgcn_fmed3f(e0.x, e0.y, 0.0f), __builtin_amdgcn_fmed3f(e1.x, e1.y, 0.0f)};
+    const v2f w23 = {__builtin_amdgcn_fmed3f(e2.x, e2.y, 0.0f), __builtin_amdgcn_fmed3f(e3.x, e3.y, 0.0f)};
+    acc2 = w01 * pa + acc2;
+    acc2 = w23 * pb + acc2;
     fi += 4.0f;
 }
 template <int F>
@@ -313,13 +314,14 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
         if (g < sch.n_groups) {
             const int L = sch.trips[g], pl = sch.part_log2[g];
             const int msub = lf & ((LPF >> pl) - 1), h = lf >> (F == 2 ? 5 - pl : 6 - pl);
-            const float cU0 = U0, cDU = DU, cD0 = D0, cDD = DD;
+            const v2f ud0 = {U0, D0}, dud = {DU, -DD};
             unsigned addr = lds_addr(row + __float_as_int(K0) + h * L);
             if (g + 1 < kMelMaxGroups && g + 1 < sch.n_groups) {
                 const float *pn = params_of(g + 1);
                 K0 = pn[0]; U0 = pn[1]; DU = pn[2]; D0 = pn[3]; DD = pn[4];
             }
-            float fi = (float)(h * L), acc = 0.0f;
+            float fi = (float)(h * L);
+            v2f acc2 = {0.0f, 0.0f};
             // trips are multiples of 4 (host-padded): four bins per step, the next four already in
             // flight in the other register set (A/B ping-pong, two steps per iteration); a step's
             // prefetch may read <= 4 floats past the slice (inside the scratch, never used) and
@@ -335,19 +337,20 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
                     mel_lds_read2<6>(b1, addr);
                     mel_lds_wait<2>(a0, a1);
                 }
-                mel_step4(acc, fi, a0, a1, cU0, cDU, cD0, cDD);
+                mel_step4(acc2, fi, a0, a1, ud0, dud);
                 if (i + 4 < L) {
                     if (!(AA_MEL_ABL & 2)) {
                         mel_lds_read2<8>(a0, addr);
                         mel_lds_read2<10>(a1, addr);
                         mel_lds_wait<2>(b0, b1);
                     }
-                    mel_step4(acc, fi, b0, b1, cU0, cDU, cD0, cDD);
+                    mel_step4(acc2, fi, b0, b1, ud0, dud);
                 }
                 addr += 32;
             }
             mel_lds_wait<0>(a0, a1);
             mel_lds_wait<0>(b0, b1);
+            float acc = acc2.x + acc2.y;
             // sum the K-slices: h sits in the top bits of the frame's lane index
             if (pl >= 1 && !(AA_MEL_ABL & 8)) {
                 if (F == 1) {
