@@ -724,7 +724,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->wave512 = cfg->n_fft == 512;
             }
         }
-        if (cfg->n_fft == 2048 && cfg->hop % 64 == 0) {
+        if (cfg->n_fft == 2048 && cfg->hop % 4 == 0) {   // 16-byte staging pieces and frame reads
             int fpw = 4;
             while (fpw > 1 && aa::wave2048_lds_dwords(fpw, cfg->hop) > 16384)
                 --fpw;
@@ -738,7 +738,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->wave2048 = true;
             }
         }
-        if (cfg->n_fft == 1024 && cfg->hop % 64 == 0) {
+        if (cfg->n_fft == 1024 && cfg->hop % 4 == 0) {
             // frames per workgroup chunk: the tunable default, shrunk until the LDS need fits 64 KiB.
             int fpw = 8;
             if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))

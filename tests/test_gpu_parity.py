@@ -53,9 +53,11 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 
 def test_kernel_selection(aa):
     assert aa.Stft(1024, 256).kernel == "wave1024"
-    assert aa.Stft(1024, 100).kernel == "lds_radix2"     # hop not a multiple of 64
+    assert aa.Stft(1024, 100).kernel == "wave1024"          # any hop that keeps 16-byte staging pieces
+    assert aa.Stft(1024, 101).kernel == "lds_radix2"
     assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
-    assert aa.Stft(2048, 500).kernel == "lds_radix2"
+    assert aa.Stft(2048, 500).kernel == "wave2048"
+    assert aa.Stft(2048, 502).kernel == "lds_radix2"
     assert aa.Stft(256, 64).kernel == "wave256"             # onset geometry (onset.rs:122-123)
     assert aa.Stft(256, 63).kernel == "lds_radix2"
     assert aa.Stft(512, 128).kernel == "wave512"
@@ -84,7 +86,7 @@ def test_wave1024_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
     assert nerr(got, tru).max() < TOL_VS_TRUTH
 
 
-@pytest.mark.parametrize("hop", [64, 128, 256, 512, 1024, 1088])
+@pytest.mark.parametrize("hop", [4, 36, 64, 100, 128, 256, 500, 512, 1024, 1088])
 def test_wave1024_hops(aa, oracle_mod, torch_mod, hop):
     n = 1024
     rng = np.random.default_rng(hop)
@@ -116,7 +118,7 @@ def test_wave2048_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
     assert nerr(got, tru).max() < TOL_VS_TRUTH
 
 
-@pytest.mark.parametrize("hop", [64, 512, 1024, 2048])
+@pytest.mark.parametrize("hop", [4, 64, 100, 500, 512, 1024, 2048])
 def test_wave2048_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
     n = 2048
     x = aa.signals.synth_corpus(999, n + 50 * hop + 3)
@@ -232,7 +234,7 @@ def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
 
 # -------------------------------------------------------------------- generic paths --
 @pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 126),
-                                   (1024, 100), (2048, 500), (4096, 1024), (8192, 4096)])
+                                   (1024, 101), (2048, 502), (4096, 1024), (8192, 4096)])
 @pytest.mark.parametrize("output", ["mag", "complex"])
 def test_lds_radix2_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
     rng = np.random.default_rng(n + hop)
