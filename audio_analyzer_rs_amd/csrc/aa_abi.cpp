@@ -368,11 +368,11 @@ void build_wave_small_table(int n_fft, const float *window, std::vector<float> *
 {
     tab->assign((size_t)aa::kWave256Rows * 64, 0.0f);
     float *T = tab->data();
-    const int M = n_fft / 2, LPF = M / 8, FPW = 64 / LPF, stages = LPF == 16 ? 1 : 2, PPF = M / 2 + 1;
+    const int M = n_fft / 2, LPF = M / 8, FPW = 64 / LPF, stages = LPF == 8 ? 0 : LPF == 16 ? 1 : 2, PPF = M / 2 + 1;
     for (int lane = 0; lane < 64; ++lane) {
         // before the exchange: lane = 8 q' + gamma, gamma = (frame, c); q = q' + 8 bitrev(c)
         const int gam = lane & 7, c = gam & ((1 << stages) - 1), qp = lane >> 3;
-        const int crev = stages == 1 ? c : (((c & 1) << 1) | (c >> 1));
+        const int crev = stages < 2 ? c : (((c & 1) << 1) | (c >> 1));
         const int q = qp + 8 * crev;
         for (int j = 0; j < 8; ++j)
             for (int cc = 0; cc < 2; ++cc)
@@ -426,6 +426,7 @@ struct aa_stft_plan {
     bool wave1024 = false;
     bool wave256 = false;
     bool wave512 = false;
+    bool wave128 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
     // mel / MFCC post-ops (build-defined)
@@ -706,13 +707,13 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->ws_logmel_rows = kMelSlab;
             }
         }
-        if ((cfg->n_fft == 256 || cfg->n_fft == 512) && cfg->hop % 4 == 0) {
-            // chunk = 8 groups of FPW frames (two per wave): 32 frames at 256, 16 at 512; shrink in
-            // steps of 4 groups to fit 64 KiB
-            const int fpwave = cfg->n_fft == 256 ? 4 : 2;
+        if ((cfg->n_fft == 128 || cfg->n_fft == 256 || cfg->n_fft == 512) && cfg->hop % 4 == 0) {
+            // chunk = 8 groups of FPW frames (two per wave): 64 / 32 / 16 frames at 128 / 256 / 512;
+            // halved until the staging fits 64 KiB
+            const int fpwave = 1024 / cfg->n_fft;   // frames per wave pass: 8 / 4 / 2
             int fpw = 8 * fpwave;
-            while (fpw > 4 * fpwave && aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) > 16384)
-                fpw -= 4 * fpwave;
+            while (fpw > fpwave && aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) > 16384)
+                fpw /= 2;                           // 8 -> 4 -> 2 -> 1 groups (long hops: some waves idle)
             if (aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) <= 16384) {
                 std::vector<float> tab;
                 build_wave_small_table(cfg->n_fft, p->window_host.data(), &tab);
@@ -722,6 +723,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->frames_per_wg = fpw;
                 p->wave256 = cfg->n_fft == 256;
                 p->wave512 = cfg->n_fft == 512;
+                p->wave128 = cfg->n_fft == 128;
             }
         }
         if (cfg->n_fft == 2048 && cfg->hop % 4 == 0) {   // 16-byte staging pieces and frame reads
@@ -836,6 +838,8 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "wave256";
     if (p->wave512)
         return "wave512";
+    if (p->wave128)
+        return "wave128";
     return p->tabs.pow2 ? "lds_radix2" : "dft";
 }
 
@@ -867,7 +871,7 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st));
-        } else if ((p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+        } else if ((p->wave128 || p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave_small(p->cfg.n_fft, kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                          p->frames_per_wg, p->log_floor, st));
         } else if (p->wave2048 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {

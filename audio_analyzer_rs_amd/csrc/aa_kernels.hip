@@ -1127,10 +1127,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
     }
 }
 
-// ------------------------------------- several frames per wave, n_fft = 256 and 512 --
+// -------------------------------- several frames per wave, n_fft = 128, 256 and 512 --
 // 256/64 is the onset geometry of the reference (src/analysis/onset.rs:122-123); 512 shares the
-// structure.  M = n_fft/2 complex points per frame on LPF = M/8 lanes (16 / 32) with 8 points per
-// lane, so a wave transforms FPW = 64/LPF frames (4 / 2) at once:
+// structure (and 128, with no DPP stage at all).  M = n_fft/2 complex points per frame on LPF = M/8
+// lanes (8 / 16 / 32) with 8 points per lane, so a wave transforms FPW = 64/LPF frames (8 / 4 / 2):
 //   z[m], m = LPF j + q:  lane holds q, register j (0..7)
 //   pass A   radix-8 over j in registers, x W_M^(q k1)                    -> Y'[q][k1]
 //   stages   the LPF-point transform over q = q' + 8 c: log2(LPF) - 3 radix-2 DIF butterflies
@@ -1152,10 +1152,12 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
 // 30..33 stage twiddles, 36..37 stage signs, 40..49 -i W_N^k of the lane's five pairs.
 template <int N>
 struct WaveSmall {
-    static constexpr int M = N / 2, LPF = M / 8, FPW = 64 / LPF, STAGES = (LPF == 16) ? 1 : 2;
+    static constexpr int M = N / 2, LPF = M / 8, FPW = 64 / LPF, STAGES = (LPF == 8) ? 0 : (LPF == 16) ? 1 : 2;
     static constexpr int NB = M + 1, PPF = M / 2 + 1, PAIRS = FPW * PPF;
-    static constexpr int STRIP = (N == 256) ? 144 : 264;   // complex per frame (>= NB, even; 256: 2*144 = 32 mod 64)
-    static constexpr int GROUP_STORES = (N == 256) ? 3 : 5;
+    // complex per frame in the strip (>= NB, even; 256: 2*144 = 32 mod 64 keeps two frames apart)
+    static constexpr int STRIP = (N == 128) ? 72 : (N == 256) ? 144 : 264;
+    static constexpr int ROW_FLOATS = FPW * NB;            // 520 / 516 / 514: the dense row image
+    static constexpr int GROUP_STORES = (N == 512) ? 5 : 3;
 };
 
 template <int CTRL, int BANK_MASK>
@@ -1166,7 +1168,7 @@ __device__ __forceinline__ v2f dpp_pair(v2f old, v2f src)
 template <int N, int BYTE_OFF>
 __device__ __forceinline__ v2f small_frame_read(unsigned fr)
 {
-    return lds_read_b64<BYTE_OFF * (N / 256)>(fr);
+    return lds_read_b64<BYTE_OFF * N / 256>(fr);
 }
 template <int N, int OUT, bool WIDE>
 __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
@@ -1182,7 +1184,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // lane map before the exchange E (frame read, pass A, stages) and after it (split, store)
     const int gam = lane & 7, cA = gam & ((1 << G::STAGES) - 1);
-    const int crev = G::STAGES == 1 ? cA : (((cA & 1) << 1) | (cA >> 1));
+    const int crev = G::STAGES < 2 ? cA : (((cA & 1) << 1) | (cA >> 1));
     const int fqA = gam >> G::STAGES, qA = 8 * crev + (lane >> 3);
     const int fqB = lane / LPF, lB = lane % LPF;
 
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         // two groups of FPW frames (GROUP_STORES stores each) after issuing this chunk's DMA loads
         if (c == c0 || groups_per_wave != 2 || frames_per_wg != 8 * FPW || OUT == kComplex || !WIDE)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (N == 256)
+        else if (G::GROUP_STORES == 3)
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -1287,11 +1289,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
                 v[k] = pk_cmul(v[k], twA[k]);
 
             // ---- radix-2 DIF stages across lane bits 0 (and 1): partner in the same quad ----
-            hazard_fence(v);
+            if (G::STAGES >= 1) {
+                hazard_fence(v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);        // quad_perm [1,0,3,2]: lane ^ 1
-                v[k] = pk_cmul(v[k] * sig[0] + p, wst[0]);
+                for (int k = 0; k < 8; ++k) {
+                    v2f p = dpp_pair<0xB1, 0xF>(v[k], v[k]);    // quad_perm [1,0,3,2]: lane ^ 1
+                    v[k] = pk_cmul(v[k] * sig[0] + p, wst[0]);
+                }
             }
             if (G::STAGES == 2) {
                 hazard_fence(v);
@@ -1343,15 +1347,15 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             }
             if (OUT != kComplex) {
                 __builtin_amdgcn_wave_barrier();
-                if (WIDE && nvalid == FPW && N == 256) {
-                    // 516 floats = 129 float4, group start 16-byte aligned
+                if (WIDE && nvalid == FPW && G::ROW_FLOATS % 4 == 0) {
+                    // 520 / 516 floats = 130 / 129 float4, group start 16-byte aligned
                     v4f b0 = *reinterpret_cast<const v4f *>(scrf + 4 * lane);
                     v4f b1 = *reinterpret_cast<const v4f *>(scrf + 256 + 4 * lane);
-                    v4f b2 = *reinterpret_cast<const v4f *>(scrf + 512);
+                    v4f b2 = *reinterpret_cast<const v4f *>(scrf + 512 + 4 * (lane & 1));
                     __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(grp + 4 * lane));
                     __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(grp + 256 + 4 * lane));
-                    if (lane == 0)
-                        __builtin_nontemporal_store(b2, reinterpret_cast<v4f *>(grp + 512));
+                    if (4 * lane < G::ROW_FLOATS - 512)
+                        __builtin_nontemporal_store(b2, reinterpret_cast<v4f *>(grp + 512 + 4 * lane));
                 } else if (WIDE && nvalid == FPW) {
                     // 514 floats = 257 float2, group start 8-byte aligned
 #pragma unroll
@@ -1755,6 +1759,8 @@ hipError_t launch_wave_small(int n_fft, int out_kind, const float *x, float *out
                              int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                              float log_floor, hipStream_t stream)
 {
+    if (n_fft == 128)
+        return launch_wave_small_n<128>(out_kind, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     if (n_fft == 256)
         return launch_wave_small_n<256>(out_kind, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream);
     if (n_fft == 512)

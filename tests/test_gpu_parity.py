@@ -61,6 +61,7 @@ def test_kernel_selection(aa):
     assert aa.Stft(256, 64).kernel == "wave256"             # onset geometry (onset.rs:122-123)
     assert aa.Stft(256, 63).kernel == "lds_radix2"
     assert aa.Stft(512, 128).kernel == "wave512"
+    assert aa.Stft(128, 32).kernel == "wave128"
     assert aa.Stft(512, 126).kernel == "lds_radix2"
     assert aa.Stft(1000, 250).kernel == "dft"
 
@@ -134,10 +135,10 @@ def test_wave2048_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
 
 @pytest.mark.parametrize("n_frames", [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4099])
 @pytest.mark.parametrize("output", ["mag", "complex"])
-@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("n", [128, 256, 512])
 def test_wave256_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output, n):
     """The onset geometry (256 / 64, src/analysis/onset.rs:122-123): four frames per wave; the same
-    kernel structure at 512 / 128 (two frames per wave)."""
+    kernel structure at 512 / 128 (two frames per wave) and 128 / 32 (eight)."""
     hop = n // 4
     rng = np.random.default_rng(300 + n_frames + n)
     L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
@@ -154,7 +155,7 @@ def test_wave256_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output, n):
 
 
 @pytest.mark.parametrize("hop", [4, 32, 64, 128, 256, 300])
-@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("n", [128, 256, 512])
 def test_wave256_hops_and_outputs(aa, oracle_mod, torch_mod, hop, n):
     x = aa.signals.synth_corpus(555, n + 200 * hop + 1)
     w = oracle_mod.hann_window(n)
@@ -209,7 +210,7 @@ def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
     rng = np.random.default_rng(20260101)
     seen = set()
     for case in range(60):
-        n = int(rng.choice([256, 512, 1024, 2048, 64, 4096, 1000]))
+        n = int(rng.choice([128, 256, 512, 1024, 2048, 64, 4096, 1000]))
         hop = int(rng.choice([n // 4, n // 2, n // 8, n, 64, 192, 100, 37, int(rng.integers(1, n + 50))]))
         hop = max(hop, 1)
         output = str(rng.choice(["mag", "power", "complex"]))
@@ -229,7 +230,7 @@ def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
         if f1 > f0:
             tol = TOL_VS_TRUTH * (2 if output == "power" else 1)
             assert nerr(got, ref).max() < tol, (case, n, hop, output, f0, f1, plan.kernel)
-    assert {"wave1024", "wave2048", "wave256", "wave512", "lds_radix2", "dft"} <= seen
+    assert {"wave1024", "wave2048", "wave256", "wave512", "wave128", "lds_radix2", "dft"} <= seen
 
 
 # -------------------------------------------------------------------- generic paths --

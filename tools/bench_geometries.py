@@ -17,7 +17,7 @@ x = aa.signals.synth_corpus(0, 28_800_000)
 xd = torch.from_numpy(x).cuda()
 cases = [
     (1024, 256, "mag", {}), (1024, 256, "complex", {}), (2048, 512, "mag", {}), (2048, 512, "complex", {}),
-    (256, 64, "mag", {}), (512, 128, "mag", {}), (4096, 1024, "mag", {}),
+    (256, 64, "mag", {}), (512, 128, "mag", {}), (128, 32, "mag", {}), (4096, 1024, "mag", {}),
     (2048, 512, "logmel", dict(n_mels=128)), (1024, 256, "logmel", dict(n_mels=128)),
     (1024, 256, "mfcc", dict(n_mels=128, n_mfcc=40)),
     (2048, 512, "logmel", dict(n_mels=128, gemm=1)), (1024, 256, "mfcc", dict(n_mels=128, n_mfcc=40, gemm=1)),
