@@ -1105,8 +1105,8 @@ int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, i
     if (!mags_dev || !eff_floor_dev || !out_freq_dev || !out_score_dev || !out_count_dev || n_frames < 0 ||
         n_bins < 3 || !(bin_width > 0.0f))
         return fail(AA_ERR_ARG, "aa_tuner_pitches_device: bad argument");
-    if (n_bins > 4097)
-        return fail(AA_ERR_UNSUPPORTED, "aa_tuner_pitches_device: n_bins > 4097 is not built (got %d)", n_bins);
+    if (n_bins > 1537)   // two rows + six per-peak arrays of n_bins floats in 64 KiB of LDS
+        return fail(AA_ERR_UNSUPPORTED, "aa_tuner_pitches_device: n_bins > 1537 is not built (got %d)", n_bins);
     AA_HIP(aa::launch_tuner_pitches(mags_dev, eff_floor_dev, n_frames, n_bins, bin_width, min_freq, max_freq,
                                     out_freq_dev, out_score_dev, out_count_dev, (hipStream_t)stream));
     return AA_OK;

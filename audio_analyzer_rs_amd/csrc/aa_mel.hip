@@ -737,7 +737,7 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
     int max_bin = (int)floorf(max_freq / bin_width);
     if (max_bin > n_bins - 2)
         max_bin = n_bins - 2;
-    const int max_peaks = n_bins / 2 + 2;
+    const int max_peaks = n_bins;                    // plateaus can make neighbouring bins peaks
     const int nbp = (n_bins + 3) & ~3;
     const size_t lds = sizeof(float) * (size_t)(2 * nbp + 8 * max_peaks) + (size_t)nbp;
     if (lds > 64 * 1024)

@@ -230,7 +230,8 @@ int aa_tuner_floor_device(const float *mags_dev, int64_t n_frames, int32_t n_bin
  * 24 Hz and 10 kHz, stft.rs:173-174; bin_width = sample_rate / n_fft, :320), parabolic
  * log-magnitude interpolation, harmonic-sum score over up to 14 harmonics, 50 % score cutoff,
  * harmonic-ghost suppression, descending score, 2-bin dedupe, at most 8 notes.
- * out_freq_dev / out_score_dev: [n_frames][8] (unused slots 0), out_count_dev: notes per frame.
+ * out_freq_dev / out_score_dev: [n_frames][8] (unused slots 0), out_count_dev: notes per frame;
+ * n_bins <= 1537 (the rows of one frame and its peak lists live in one wave's LDS).
  * f32 in the reference's operation order; ln / log2 come from the device math library, so scores
  * match a CPU evaluation to ~1e-6 relative and a decision can only flip on an exact tie; equal
  * scores keep ascending bin order (the reference's sort_unstable_by leaves it unspecified).

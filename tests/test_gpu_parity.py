@@ -539,6 +539,15 @@ def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
     assert np.allclose(freq[same], rf[same], rtol=1e-5, atol=0.0)
     assert np.allclose(score[same], rs[same], rtol=1e-5, atol=1e-6)
     assert np.all(freq[np.arange(8)[None, :] >= count[:, None]] == 0.0)
+    # degenerate spectra: plateaus make every bin a peak (more peaks than bins / 2), zeros, huge values
+    flat = torch_mod.full((3, nb), 2.0, device="cuda")
+    flat[1] = 0.0
+    flat[2, ::2] = 1e30
+    fl = torch_mod.full((3, nb), 0.1, device="cuda")
+    f2, s2, c2 = aa.tuner_pitches(flat, fl, sr / n)
+    r2 = oracle_mod.extract_pitches(flat.cpu().numpy(), fl.cpu().numpy(), sr / n)
+    assert np.array_equal(c2.cpu().numpy(), r2[2])
+    assert np.allclose(f2.cpu().numpy(), r2[0], rtol=1e-5) and np.allclose(s2.cpu().numpy(), r2[1], rtol=1e-5)
 
 
 def test_tuner_noise_floor_bit_exact(aa, oracle_mod, torch_mod):
