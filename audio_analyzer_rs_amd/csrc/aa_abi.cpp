@@ -65,7 +65,7 @@ int build_fft_tables(int n, FftTables *t)
     const int m = n / 2;
     t->n = n;
     t->pow2 = is_pow2(n);
-    const int ntw = t->pow2 ? (m / 2 > 0 ? m / 2 : 1) : m;
+    const int ntw = m;   // W_m^q, q < m (the Stockham passes index up to (R-1)/R of the circle)
     std::vector<float> a(2 * (size_t)ntw), b(2 * (size_t)(m / 2 + 1));
     for (int q = 0; q < ntw; ++q) {
         double ang = -2.0 * kPi * (double)q / (double)m;
@@ -840,7 +840,7 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "wave512";
     if (p->wave128)
         return "wave128";
-    return p->tabs.pow2 ? "lds_radix2" : "dft";
+    return p->tabs.pow2 ? "lds_stockham" : "dft";
 }
 
 int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,

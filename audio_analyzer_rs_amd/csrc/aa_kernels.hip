@@ -1427,13 +1427,70 @@ __device__ __forceinline__ void split_and_store(const float2 *Z, const float2 *t
     }
 }
 
-// LDS Stockham radix-2, one workgroup per frame, any power-of-two n >= 4.
+// R-point forward DFT in place, natural order (R = 2, 4, 8), plain float2.
+template <int R>
+__device__ __forceinline__ void small_dft(float2 (&v)[R])
+{
+    if (R == 2) {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    } else if (R == 4) {
+        const float2 a0 = cadd(v[0], v[2]), b0 = csub(v[0], v[2]);
+        const float2 a1 = cadd(v[1], v[3]), b1 = csub(v[1], v[3]);
+        const float2 jb1 = make_float2(b1.y, -b1.x);            // -i b1
+        v[0] = cadd(a0, a1);
+        v[2] = csub(a0, a1);
+        v[1] = cadd(b0, jb1);
+        v[3] = csub(b0, jb1);
+    } else {
+        const float h = 0.70710678118654752440f;
+        float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        small_dft<4>(e);
+        small_dft<4>(o);
+        const float2 o1 = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));    // W8^1 o1
+        const float2 o2 = make_float2(o[2].y, -o[2].x);                                 // W8^2 o2
+        const float2 o3 = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));   // W8^3 o3
+        v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+        v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
+        v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
+    }
+}
+// One Stockham (autosort) pass of radix R over m points: sub-transforms of size ns -> ns R.
+// tw_m holds W_m^q for q < m.
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2 *A, float2 *B, const float2 *__restrict__ tw_m,
+                                              int m, int ns)
+{
+    const int mr = m / R, tstep = m / (ns * R);
+    for (int j = threadIdx.x; j < mr; j += blockDim.x) {
+        const int k = j & (ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[r] = A[j + r * mr];
+        if (ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                v[r] = cmul(v[r], tw_m[r * k * tstep]);
+        }
+        small_dft<R>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            B[j0 + r * ns] = v[r];
+    }
+}
+
+// LDS Stockham FFT, one workgroup per frame, any power-of-two n >= 4: radix-8 passes, then one
+// radix-4 or radix-2 pass for what is left (2048 complex points: 4 passes instead of 11).
 template <int OUT>
-__global__ void stft_lds_radix2_kernel(const float *__restrict__ x, float *__restrict__ out,
-                                       const float *__restrict__ window,
-                                       const float2 *__restrict__ tw_m,
-                                       const float2 *__restrict__ tw_split, int n,
-                                       int64_t frame_begin, int64_t hop, float log_floor)
+__global__ void stft_lds_stockham_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                         const float *__restrict__ window,
+                                         const float2 *__restrict__ tw_m,
+                                         const float2 *__restrict__ tw_split, int n,
+                                         int64_t frame_begin, int64_t hop, float log_floor)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m = n >> 1;
@@ -1450,21 +1507,23 @@ __global__ void stft_lds_radix2_kernel(const float *__restrict__ x, float *__res
         A[i] = make_float2(a, b);
     }
     __syncthreads();
-    const int half = m >> 1;
-    for (int ns = 1; ns < m; ns <<= 1) {
-        const int tstep = half / ns;
-        for (int i = threadIdx.x; i < half; i += blockDim.x) {
-            const int k = i & (ns - 1);
-            float2 a = A[i];
-            float2 b = cmul(A[i + half], tw_m[k * tstep]);
-            const int j = ((i - k) << 1) + k;
-            B[j] = cadd(a, b);
-            B[j + ns] = csub(a, b);
-        }
+    int ns = 1;
+    while (m / ns >= 8) {
+        stockham_pass<8>(A, B, tw_m, m, ns);
+        ns *= 8;
         __syncthreads();
         float2 *tmp = A;
         A = B;
         B = tmp;
+    }
+    if (m / ns == 4) {
+        stockham_pass<4>(A, B, tw_m, m, ns);
+        __syncthreads();
+        A = B;
+    } else if (m / ns == 2) {
+        stockham_pass<2>(A, B, tw_m, m, ns);
+        __syncthreads();
+        A = B;
     }
     const int cols = (OUT == kComplex) ? 2 * (m + 1) : (m + 1);
     split_and_store<OUT>(A, tw_split, m, out + t * (int64_t)cols, log_floor);
@@ -1792,7 +1851,7 @@ hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float
     default: return hipErrorInvalidValue;                                                      \
     }
     if (pow2) {
-        AA_SWITCH_GEN(stft_lds_radix2_kernel)
+        AA_SWITCH_GEN(stft_lds_stockham_kernel)
     } else {
         AA_SWITCH_GEN(stft_dft_kernel)
     }

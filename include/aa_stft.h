@@ -138,7 +138,7 @@ int aa_stft_plan_destroy(aa_stft_plan *plan);
 int64_t aa_stft_num_frames(const aa_stft_plan *plan, int64_t n_samples);
 /* floats per output row for the plan's output kind. */
 int32_t aa_stft_out_cols(const aa_stft_plan *plan);
-/* Name of the kernel path the plan selected ("wave1024", "lds_radix2", "dft"). */
+/* Name of the kernel path the plan selected ("wave1024", "lds_stockham", "dft"). */
 const char *aa_stft_kernel_name(const aa_stft_plan *plan);
 
 /* Frames [frame_begin, frame_end) of the buffer `samples_dev[0 .. n_samples)`,

@@ -54,15 +54,15 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 def test_kernel_selection(aa):
     assert aa.Stft(1024, 256).kernel == "wave1024"
     assert aa.Stft(1024, 100).kernel == "wave1024"          # any hop that keeps 16-byte staging pieces
-    assert aa.Stft(1024, 101).kernel == "lds_radix2"
+    assert aa.Stft(1024, 101).kernel == "lds_stockham"
     assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
     assert aa.Stft(2048, 500).kernel == "wave2048"
-    assert aa.Stft(2048, 502).kernel == "lds_radix2"
+    assert aa.Stft(2048, 502).kernel == "lds_stockham"
     assert aa.Stft(256, 64).kernel == "wave256"             # onset geometry (onset.rs:122-123)
-    assert aa.Stft(256, 63).kernel == "lds_radix2"
+    assert aa.Stft(256, 63).kernel == "lds_stockham"
     assert aa.Stft(512, 128).kernel == "wave512"
     assert aa.Stft(128, 32).kernel == "wave128"
-    assert aa.Stft(512, 126).kernel == "lds_radix2"
+    assert aa.Stft(512, 126).kernel == "lds_stockham"
     assert aa.Stft(1000, 250).kernel == "dft"
 
 
@@ -230,18 +230,18 @@ def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
         if f1 > f0:
             tol = TOL_VS_TRUTH * (2 if output == "power" else 1)
             assert nerr(got, ref).max() < tol, (case, n, hop, output, f0, f1, plan.kernel)
-    assert {"wave1024", "wave2048", "wave256", "wave512", "wave128", "lds_radix2", "dft"} <= seen
+    assert {"wave1024", "wave2048", "wave256", "wave512", "wave128", "lds_stockham", "dft"} <= seen
 
 
 # -------------------------------------------------------------------- generic paths --
 @pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 126),
                                    (1024, 101), (2048, 502), (4096, 1024), (8192, 4096)])
 @pytest.mark.parametrize("output", ["mag", "complex"])
-def test_lds_radix2_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
+def test_lds_stockham_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
     rng = np.random.default_rng(n + hop)
     x = rng.standard_normal(n + 40 * hop + 1).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == "lds_radix2"
+    assert plan.kernel == "lds_stockham"
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
     tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
