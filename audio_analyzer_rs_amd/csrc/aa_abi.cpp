@@ -411,6 +411,8 @@ struct aa_fft_plan {
     FftTables tabs;
     float *d_in = nullptr;   // one frame
     float *d_out = nullptr;  // one spectrum
+    // batches of back-to-back frames (hop = len, no window) on the wave kernels, when len has one
+    struct aa_stft_plan *batch = nullptr;
 };
 
 struct aa_stft_plan {
@@ -507,6 +509,15 @@ int aa_fft_create(int len, aa_fft_plan **out_plan)
             rc = fail(AA_ERR_HIP, "hipMalloc(frame buffers): %s",
                       hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
+    if (rc == AA_OK && (len == 128 || len == 256 || len == 512 || len == 1024 || len == 2048)) {
+        aa_stft_config cfg{};
+        cfg.n_fft = len;
+        cfg.hop = len;
+        cfg.window = AA_WINDOW_RECT;
+        cfg.output = AA_OUT_COMPLEX;
+        if (aa_stft_plan_create(&cfg, nullptr, &p->batch) != AA_OK)
+            p->batch = nullptr;            // the generic kernel still serves the batch calls
+    }
     if (rc != AA_OK) {
         aa_fft_destroy(p);
         return rc;
@@ -521,6 +532,8 @@ int aa_fft_destroy(aa_fft_plan *p)
         return AA_OK;
     DeviceGuard g(p->device);
     free_fft_tables(&p->tabs);
+    if (p->batch)
+        aa_stft_plan_destroy(p->batch);
     if (p->d_in)
         (void)hipFree(p->d_in);
     if (p->d_out)
@@ -539,6 +552,10 @@ int aa_fft_forward_batch_device(aa_fft_plan *p, const float *in_dev, float *out_
     DeviceGuard g(p->device);
     if (!g.ok)
         return fail(AA_ERR_HIP, "cannot select device %d", p->device);
+    // frames back to back = an STFT with hop = len and no window: the wave kernels take it when
+    // the input is 16-byte aligned, the generic kernel otherwise
+    if (p->batch && batch > 0 && (reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0)
+        return aa_stft_execute_device(p->batch, in_dev, batch * (int64_t)p->len, 0, batch, out_dev, stream);
     AA_HIP(aa::launch_generic_forward(p->tabs.pow2, aa::kComplex, in_dev, out_dev, nullptr,
                                       p->tabs.tw_m, p->tabs.tw_split, p->len, 0, batch, p->len,
                                       1e-10f, (hipStream_t)stream));

@@ -589,12 +589,18 @@ def test_fft_processor_forward_inverse(aa, oracle_mod, n):
     assert np.max(np.abs(y - yo)) / np.max(np.abs(yo)) < TOL_VS_ORACLE
 
 
-def test_fft_processor_batch_device(aa, torch_mod):
-    n, batch = 2048, 300
+@pytest.mark.parametrize("n,batch", [(2048, 300), (1024, 77), (512, 33), (256, 1000), (128, 5), (4096, 9), (100, 12)])
+def test_fft_processor_batch_device(aa, torch_mod, n, batch):
+    """Batches of back-to-back frames: the wave kernels (hop = len, no window) for 128..2048, the
+    generic kernels otherwise - and for a batch that does not start 16-byte aligned."""
     g = torch_mod.Generator(device="cuda").manual_seed(1)
     frames = torch_mod.randn((batch, n), generator=g, device="cuda", dtype=torch_mod.float32)
     fft = aa.FftProcessor(n)
     X = fft.forward_batch(frames)
+    if n % 4 == 0 and batch > 2:
+        odd = torch_mod.empty(batch * n + 1, device="cuda")[1:].view(batch, n)      # 4-byte aligned only
+        odd.copy_(frames)
+        assert torch_mod.allclose(fft.forward_batch(odd), X, rtol=0, atol=2e-5 * float(X.abs().max()))
     T = torch_mod.fft.rfft(frames.double(), dim=-1)
     err = ((X.to(torch_mod.complex128) - T).abs().amax(dim=1) / T.abs().amax(dim=1)).max().item()
     assert err < TOL_VS_TRUTH
