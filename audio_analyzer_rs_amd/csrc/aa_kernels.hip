@@ -1404,19 +1404,21 @@ __device__ __forceinline__ void store_bin(float *row, int k, float re, float im,
 }
 
 // Real-FFT split of an m-point complex spectrum Z (in LDS) into n/2+1 bins.
-template <int OUT>
+// PAD: Z is stored at index i + (i >> 3) (the bank-conflict padding of stft_wg_kernel).
+template <int OUT, bool PAD = false>
 __device__ __forceinline__ void split_and_store(const float2 *Z, const float2 *tw_split, int m,
                                                 float *row, float log_floor)
 {
+    auto at = [&](int i) { return Z[PAD ? i + (i >> 3) : i]; };
     for (int k = threadIdx.x; 2 * k <= m; k += blockDim.x) {
         if (k == 0) {
-            float2 z = Z[0];
+            float2 z = at(0);
             store_bin<OUT>(row, 0, z.x + z.y, 0.0f, log_floor);
             store_bin<OUT>(row, m, z.x - z.y, 0.0f, log_floor);
             continue;
         }
         const int kk = m - k;
-        float2 a = Z[k], p = Z[kk];
+        float2 a = at(k), p = at(kk);
         float2 bc = make_float2(p.x, -p.y);
         float2 e = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
         float2 o = make_float2(0.5f * (a.x - bc.x), 0.5f * (a.y - bc.y));
@@ -1527,6 +1529,165 @@ __global__ void stft_lds_stockham_kernel(const float *__restrict__ x, float *__r
     }
     const int cols = (OUT == kComplex) ? 2 * (m + 1) : (m + 1);
     split_and_store<OUT>(A, tw_split, m, out + t * (int64_t)cols, log_floor);
+}
+
+// Large frames (n_fft 4096 / 8192: M = 2048 / 4096 complex points): one persistent workgroup of
+// 256 threads per frame in flight, the same Stockham passes as stft_lds_stockham_kernel, but
+//   * every thread keeps the twiddles and window values of ITS butterflies in registers for the
+//     kernel's lifetime (they do not depend on the frame; the generic kernel gathers them from
+//     global memory for every butterfly, which is what it is bound by),
+//   * the first pass reads the samples straight from global memory (a wave reads 64 consecutive
+//     complex points per load) and the next frame's samples are fetched into registers before
+//     the passes of the current frame,
+//   * radix-8 passes: 2048 = 8 x 8 x 8 x 4, 4096 = 8 x 8 x 8 x 8.
+template <int LOGM>
+struct WgFft {
+    static constexpr int M = 1 << LOGM, T = 256, PTS = M / T;            // 8 / 16 points per thread
+    static constexpr int LAST = (LOGM % 3 == 0) ? 8 : (LOGM % 3 == 2 ? 4 : 2);   // radix of the last pass
+    static constexpr int NPASS8 = (LOGM % 3 == 0) ? LOGM / 3 - 1 : LOGM / 3;     // radix-8 passes before it
+};
+template <int LOGM, int OUT>
+__global__ __launch_bounds__(256) void stft_wg_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                      const float *__restrict__ window,
+                                                      const float2 *__restrict__ tw_m,
+                                                      const float2 *__restrict__ tw_split, int64_t frame_begin,
+                                                      int64_t n_frames, int64_t hop, float log_floor)
+{
+    using G = WgFft<LOGM>;
+    constexpr int M = G::M, T = G::T, PTS = G::PTS, B8 = PTS / 8;   // radix-8 butterflies per thread and pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // The Stockham scatter of the first two passes strides 8 / 64 points between neighbouring
+    // threads (8- and 4-way bank conflicts); storing point i at i + (i >> 3) spreads both the
+    // scatters and the unit-stride gathers over all banks.  9/8 of 2 x M points must fit 64 KiB.
+    constexpr bool PAD = (2 * (M + M / 8) * 8 <= 65536);
+    constexpr int MP = PAD ? M + M / 8 : M;
+    auto ix = [](int i) { return PAD ? i + (i >> 3) : i; };
+    float2 *bufA = reinterpret_cast<float2 *>(smem), *bufB = bufA + MP;
+    const int tid = threadIdx.x;
+    constexpr int cols = (OUT == kComplex) ? 2 * (M + 1) : (M + 1);
+
+    // ---- per-thread constants: window of its first-pass points, twiddles of its butterflies ----
+    float2 win[PTS];
+#pragma unroll
+    for (int u = 0; u < B8; ++u)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = tid + T * u + r * (M / 8);
+            win[8 * u + r] = window ? make_float2(window[2 * i], window[2 * i + 1]) : make_float2(1.0f, 1.0f);
+        }
+    float2 tw8[G::NPASS8 > 1 ? G::NPASS8 - 1 : 1][B8][7];       // radix-8 passes 2.. (the first has none)
+    {
+        int ns = 8;
+#pragma unroll
+        for (int p = 0; p < G::NPASS8 - 1; ++p) {
+#pragma unroll
+            for (int u = 0; u < B8; ++u) {
+                const int k = (tid + T * u) & (ns - 1), tstep = M / (ns * 8);
+#pragma unroll
+                for (int r = 1; r < 8; ++r)
+                    tw8[p][u][r - 1] = tw_m[r * k * tstep];
+            }
+            ns *= 8;
+        }
+    }
+    constexpr int NS_LAST = M / G::LAST, BL = (M / G::LAST) / T;  // last pass: ns and butterflies per thread
+    float2 twl[BL][G::LAST - 1];
+#pragma unroll
+    for (int u = 0; u < BL; ++u) {
+        const int k = (tid + T * u) & (NS_LAST - 1);
+#pragma unroll
+        for (int r = 1; r < G::LAST; ++r)
+            twl[u][r - 1] = tw_m[r * k];                          // tstep = M / (ns R) = 1
+    }
+
+    auto fetch = [&](int64_t t, float2 (&v)[PTS]) {
+        const float *src = x + (frame_begin + t) * hop;
+        const bool al8 = (reinterpret_cast<uintptr_t>(src) & 7u) == 0;
+#pragma unroll
+        for (int u = 0; u < B8; ++u)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + T * u + r * (M / 8);
+                if (al8)
+                    v[8 * u + r] = *reinterpret_cast<const float2 *>(src + 2 * i);
+                else
+                    v[8 * u + r] = make_float2(src[2 * i], src[2 * i + 1]);
+            }
+    };
+
+    float2 nx[PTS];
+    int64_t t = blockIdx.x;
+    if (t < n_frames)
+        fetch(t, nx);
+    for (; t < n_frames; t += gridDim.x) {
+        float2 v[PTS];
+#pragma unroll
+        for (int i = 0; i < PTS; ++i)
+            v[i] = make_float2(nx[i].x * win[i].x, nx[i].y * win[i].y);
+        if (t + gridDim.x < n_frames)
+            fetch(t + gridDim.x, nx);                            // in flight during the passes below
+        // ---- pass 1 (radix 8, ns = 1): registers -> bufA, no twiddles ----
+#pragma unroll
+        for (int u = 0; u < B8; ++u) {
+            float2 b[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                b[r] = v[8 * u + r];
+            small_dft<8>(b);
+            const int j = tid + T * u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                bufA[ix(j * 8 + r)] = b[r];
+        }
+        __syncthreads();
+        float2 *A = bufA, *B = bufB;
+        // ---- radix-8 passes 2.. ----
+        int ns = 8;
+#pragma unroll
+        for (int p = 0; p < G::NPASS8 - 1; ++p) {
+#pragma unroll
+            for (int u = 0; u < B8; ++u) {
+                const int j = tid + T * u, k = j & (ns - 1);
+                float2 b[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    b[r] = A[ix(j + r * (M / 8))];
+#pragma unroll
+                for (int r = 1; r < 8; ++r)
+                    b[r] = cmul(b[r], tw8[p][u][r - 1]);
+                small_dft<8>(b);
+                const int j0 = (j - k) * 8 + k;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    B[ix(j0 + r * ns)] = b[r];
+            }
+            __syncthreads();
+            float2 *tmp = A;
+            A = B;
+            B = tmp;
+            ns *= 8;
+        }
+        // ---- last pass (radix LAST, ns = M / LAST) ----
+#pragma unroll
+        for (int u = 0; u < BL; ++u) {
+            const int j = tid + T * u, k = j & (NS_LAST - 1);
+            float2 b[G::LAST];
+#pragma unroll
+            for (int r = 0; r < G::LAST; ++r)
+                b[r] = A[ix(j + r * (M / G::LAST))];
+#pragma unroll
+            for (int r = 1; r < G::LAST; ++r)
+                b[r] = cmul(b[r], twl[u][r - 1]);
+            small_dft<G::LAST>(b);
+            const int j0 = (j - k) * G::LAST + k;
+#pragma unroll
+            for (int r = 0; r < G::LAST; ++r)
+                B[ix(j0 + r * NS_LAST)] = b[r];
+        }
+        __syncthreads();
+        split_and_store<OUT, PAD>(B, tw_split, M, out + t * (int64_t)cols, log_floor);
+        __syncthreads();                                         // B is read above, written next frame
+    }
 }
 
 // Direct O(m^2) DFT for even lengths that are not powers of two (the reference's
@@ -1839,6 +2000,41 @@ hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float
     dim3 grid((unsigned)n_frames), block(m >= 512 ? 256 : 64);
     const float2 *twm = reinterpret_cast<const float2 *>(tw_m);
     const float2 *tws = reinterpret_cast<const float2 *>(tw_split);
+    if (pow2 && (n == 4096 || n == 8192)) {
+        // large frames: persistent workgroups with register-resident twiddles; 4096: padded buffers
+        const size_t lds = n == 4096 ? sizeof(float2) * 2 * (size_t)(m + m / 8) : sizeof(float2) * 2 * (size_t)m;
+#define AA_LAUNCH_WG(LOGM, K)                                                                              \
+    {                                                                                                      \
+        static int per_cu = 0;                                                                             \
+        if (!per_cu && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft_wg_kernel<LOGM, K>, 256, \
+                                                                    lds) != hipSuccess)                     \
+            per_cu = 1;                                                                                    \
+        int dev = 0, cus = 256;                                                                            \
+        (void)hipGetDevice(&dev);                                                                          \
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                     \
+        int64_t g = (int64_t)cus * (per_cu > 0 ? per_cu : 1);                                              \
+        if (g > n_frames)                                                                                  \
+            g = n_frames;                                                                                  \
+        hipLaunchKernelGGL((stft_wg_kernel<LOGM, K>), dim3((unsigned)g), dim3(256), lds, stream, x, out,   \
+                           window, twm, tws, frame_begin, n_frames, hop, log_floor);                       \
+    }
+#define AA_SWITCH_WG(LOGM)                                                                     \
+    switch (out_kind) {                                                                        \
+    case kComplex: AA_LAUNCH_WG(LOGM, kComplex) break;                                         \
+    case kMag: AA_LAUNCH_WG(LOGM, kMag) break;                                                 \
+    case kPower: AA_LAUNCH_WG(LOGM, kPower) break;                                             \
+    case kLogPower: AA_LAUNCH_WG(LOGM, kLogPower) break;                                       \
+    default: return hipErrorInvalidValue;                                                      \
+    }
+        if (n == 4096) {
+            AA_SWITCH_WG(11)
+        } else {
+            AA_SWITCH_WG(12)
+        }
+#undef AA_SWITCH_WG
+#undef AA_LAUNCH_WG
+        return hipGetLastError();
+    }
 #define AA_LAUNCH_GEN(KERNEL, K)                                                               \
     hipLaunchKernelGGL((KERNEL<K>), grid, block, lds, stream, x, out, window, twm, tws, n,     \
                        frame_begin, hop, log_floor)

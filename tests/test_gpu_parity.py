@@ -230,18 +230,18 @@ def test_randomised_geometry_sweep(aa, oracle_mod, torch_mod):
         if f1 > f0:
             tol = TOL_VS_TRUTH * (2 if output == "power" else 1)
             assert nerr(got, ref).max() < tol, (case, n, hop, output, f0, f1, plan.kernel)
-    assert {"wave1024", "wave2048", "wave256", "wave512", "wave128", "lds_stockham", "dft"} <= seen
+    assert {"wave1024", "wave2048", "wave256", "wave512", "wave128", "lds_stockham", "wg_stockham", "dft"} <= seen
 
 
 # -------------------------------------------------------------------- generic paths --
 @pytest.mark.parametrize("n,hop", [(8, 3), (16, 4), (64, 16), (128, 37), (256, 66), (512, 126),
-                                   (1024, 101), (2048, 502), (4096, 1024), (8192, 4096)])
+                                   (1024, 101), (2048, 502), (4096, 1024), (4096, 1001), (8192, 4096), (8192, 2048)])
 @pytest.mark.parametrize("output", ["mag", "complex"])
 def test_lds_stockham_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
     rng = np.random.default_rng(n + hop)
     x = rng.standard_normal(n + 40 * hop + 1).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == "lds_stockham"
+    assert plan.kernel == ("wg_stockham" if n >= 4096 else "lds_stockham")
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
     tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
