@@ -857,7 +857,7 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
         return "wave512";
     if (p->wave128)
         return "wave128";
-    if (p->tabs.pow2 && (p->cfg.n_fft == 4096 || p->cfg.n_fft == 8192))
+    if (p->tabs.pow2 && p->cfg.n_fft >= 1024)
         return "wg_stockham";
     return p->tabs.pow2 ? "lds_stockham" : "dft";
 }

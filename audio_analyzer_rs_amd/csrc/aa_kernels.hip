@@ -1531,18 +1531,19 @@ __global__ void stft_lds_stockham_kernel(const float *__restrict__ x, float *__r
     split_and_store<OUT>(A, tw_split, m, out + t * (int64_t)cols, log_floor);
 }
 
-// Large frames (n_fft 4096 / 8192: M = 2048 / 4096 complex points): one persistent workgroup of
-// 256 threads per frame in flight, the same Stockham passes as stft_lds_stockham_kernel, but
+// Frames the wave kernels do not take (n_fft 4096 / 8192; 1024 / 2048 with an odd hop or an
+// unaligned start): one persistent workgroup of M/8 <= 256 threads per frame in flight, the same Stockham passes as stft_lds_stockham_kernel, but
 //   * every thread keeps the twiddles and window values of ITS butterflies in registers for the
 //     kernel's lifetime (they do not depend on the frame; the generic kernel gathers them from
 //     global memory for every butterfly, which is what it is bound by),
 //   * the first pass reads the samples straight from global memory (a wave reads 64 consecutive
 //     complex points per load) and the next frame's samples are fetched into registers before
 //     the passes of the current frame,
-//   * radix-8 passes: 2048 = 8 x 8 x 8 x 4, 4096 = 8 x 8 x 8 x 8.
+//   * radix-8 passes: 512 = 8 x 8 x 8, 1024 = 8 x 8 x 8 x 2, 2048 = 8 x 8 x 8 x 4, 4096 = 8^4.
 template <int LOGM>
 struct WgFft {
-    static constexpr int M = 1 << LOGM, T = 256, PTS = M / T;            // 8 / 16 points per thread
+    static constexpr int M = 1 << LOGM, T = (M / 8 < 256) ? M / 8 : 256;  // threads per frame: 64 / 128 / 256 / 256
+    static constexpr int PTS = M / T;                                      // 8 (16 at 8192) points per thread
     static constexpr int LAST = (LOGM % 3 == 0) ? 8 : (LOGM % 3 == 2 ? 4 : 2);   // radix of the last pass
     static constexpr int NPASS8 = (LOGM % 3 == 0) ? LOGM / 3 - 1 : LOGM / 3;     // radix-8 passes before it
 };
@@ -2000,14 +2001,15 @@ hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float
     dim3 grid((unsigned)n_frames), block(m >= 512 ? 256 : 64);
     const float2 *twm = reinterpret_cast<const float2 *>(tw_m);
     const float2 *tws = reinterpret_cast<const float2 *>(tw_split);
-    if (pow2 && (n == 4096 || n == 8192)) {
-        // large frames: persistent workgroups with register-resident twiddles; 4096: padded buffers
-        const size_t lds = n == 4096 ? sizeof(float2) * 2 * (size_t)(m + m / 8) : sizeof(float2) * 2 * (size_t)m;
+    if (pow2 && n >= 1024 && n <= 8192) {
+        // persistent workgroups with register-resident twiddles; buffers padded when they fit
+        const size_t lds = n <= 4096 ? sizeof(float2) * 2 * (size_t)(m + m / 8) : sizeof(float2) * 2 * (size_t)m;
+        const int threads = m / 8 < 256 ? m / 8 : 256;
 #define AA_LAUNCH_WG(LOGM, K)                                                                              \
     {                                                                                                      \
         static int per_cu = 0;                                                                             \
-        if (!per_cu && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft_wg_kernel<LOGM, K>, 256, \
-                                                                    lds) != hipSuccess)                     \
+        if (!per_cu && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft_wg_kernel<LOGM, K>,      \
+                                                                    threads, lds) != hipSuccess)            \
             per_cu = 1;                                                                                    \
         int dev = 0, cus = 256;                                                                            \
         (void)hipGetDevice(&dev);                                                                          \
@@ -2015,8 +2017,8 @@ hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float
         int64_t g = (int64_t)cus * (per_cu > 0 ? per_cu : 1);                                              \
         if (g > n_frames)                                                                                  \
             g = n_frames;                                                                                  \
-        hipLaunchKernelGGL((stft_wg_kernel<LOGM, K>), dim3((unsigned)g), dim3(256), lds, stream, x, out,   \
-                           window, twm, tws, frame_begin, n_frames, hop, log_floor);                       \
+        hipLaunchKernelGGL((stft_wg_kernel<LOGM, K>), dim3((unsigned)g), dim3(threads), lds, stream, x,    \
+                           out, window, twm, tws, frame_begin, n_frames, hop, log_floor);                  \
     }
 #define AA_SWITCH_WG(LOGM)                                                                     \
     switch (out_kind) {                                                                        \
@@ -2026,7 +2028,11 @@ hipError_t launch_generic_forward(bool pow2, int out_kind, const float *x, float
     case kLogPower: AA_LAUNCH_WG(LOGM, kLogPower) break;                                       \
     default: return hipErrorInvalidValue;                                                      \
     }
-        if (n == 4096) {
+        if (n == 1024) {
+            AA_SWITCH_WG(9)
+        } else if (n == 2048) {
+            AA_SWITCH_WG(10)
+        } else if (n == 4096) {
             AA_SWITCH_WG(11)
         } else {
             AA_SWITCH_WG(12)

@@ -54,10 +54,10 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 def test_kernel_selection(aa):
     assert aa.Stft(1024, 256).kernel == "wave1024"
     assert aa.Stft(1024, 100).kernel == "wave1024"          # any hop that keeps 16-byte staging pieces
-    assert aa.Stft(1024, 101).kernel == "lds_stockham"
+    assert aa.Stft(1024, 101).kernel == "wg_stockham"
     assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
     assert aa.Stft(2048, 500).kernel == "wave2048"
-    assert aa.Stft(2048, 502).kernel == "lds_stockham"
+    assert aa.Stft(2048, 502).kernel == "wg_stockham"
     assert aa.Stft(256, 64).kernel == "wave256"             # onset geometry (onset.rs:122-123)
     assert aa.Stft(256, 63).kernel == "lds_stockham"
     assert aa.Stft(512, 128).kernel == "wave512"
@@ -241,7 +241,7 @@ def test_lds_stockham_vs_oracle(aa, oracle_mod, torch_mod, n, hop, output):
     rng = np.random.default_rng(n + hop)
     x = rng.standard_normal(n + 40 * hop + 1).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == ("wg_stockham" if n >= 4096 else "lds_stockham")
+    assert plan.kernel == ("wg_stockham" if n >= 1024 else "lds_stockham")
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
     tru = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
