@@ -142,6 +142,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C audio_analyzer_rs_amd/csrc`. There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch (used for device memory, streams and torch.distributed)
+    # bundles its own libamdhip64; loaded after libaa_stft.so has pulled in the system one, the two
+    # runtimes disagree about the devices ("no ROCm-capable device is detected").  Import torch
+    # first so that the library binds to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
