@@ -1007,7 +1007,10 @@ int aa_stft_execute_host(aa_stft_plan *p, const float *samples_host, int64_t n_s
     if (rc != AA_OK)
         return rc;
     const size_t row_bytes = sizeof(float) * (size_t)p->out_cols;
-    const bool fft_only = p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC;
+    // chunks on two streams may overlap: only outputs that need no plan-owned workspace qualify
+    // (the FFT outputs, and log-mel when the filterbank is fused into the FFT kernel)
+    const bool fft_only = (p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC) ||
+                          (p->cfg.output == AA_OUT_LOGMEL && p->fused_mel);
     const int64_t chunk = 16384;   // frames per pipeline stage
     if (fft_only && nf >= 2 * chunk && is_pinned_host(samples_host) && is_pinned_host(out_host)) {
         // Both buffers are page-locked (aa_host_register / hipHostMalloc): run H2D, kernel and

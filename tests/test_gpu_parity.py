@@ -673,6 +673,18 @@ def test_pinned_host_pipeline_matches_plain_host_path(aa, torch_mod):
         aa.unpin(out)
         aa.unpin(x)
     assert got is out and np.array_equal(got, plain)
+    # fused log-mel needs no plan workspace, so it rides the same pipeline
+    mel = aa.Stft(n, hop, output="logmel", sample_rate=48000, n_mels=128)
+    plain_m = mel.execute_host(x)
+    out_m = np.empty_like(plain_m)
+    aa.pin(x)
+    aa.pin(out_m)
+    try:
+        got_m = mel.execute_host(x, out=out_m)
+    finally:
+        aa.unpin(out_m)
+        aa.unpin(x)
+    assert np.array_equal(got_m, plain_m)
 
 
 # ------------------------------------------------------------------- streaming front --
