@@ -8,7 +8,7 @@ include/aa_stft.h).  Importing the package does not need a GPU; creating a plan 
 from . import _lib
 from ._lib import AaError, LIB_PATH  # noqa: F401
 from .fft import FftProcessor, hann_window  # noqa: F401
-from .stft import (PitchTracker, Stft, StftStream, downmix, onset_flux, onset_gates, pin, tuner_floor,  # noqa: F401
+from .stft import (Conditioner, PitchTracker, Stft, StftStream, downmix, global_floor_per_frame, onset_flux, onset_gates, pin, tuner_floor,  # noqa: F401
                    tuner_pitches, unpin)
 from .sharding import ShardPlan, gather_rows, scatter_samples, shard_frames, shard_samples  # noqa: F401
 from . import signals, wav  # noqa: F401

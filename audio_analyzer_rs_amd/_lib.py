@@ -114,6 +114,10 @@ SIGNATURES = {
     "aa_tuner_floor_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_conditioner_create": (ctypes.c_int, [ctypes.c_float, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "aa_conditioner_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_conditioner_process": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "aa_pitch_tracker_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "aa_pitch_tracker_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_pitch_tracker_process": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

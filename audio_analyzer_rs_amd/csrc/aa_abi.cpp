@@ -1180,6 +1180,183 @@ int aa_tuner_floor_batch_device(const float *mags_dev, const int64_t *frame_offs
     return AA_OK;
 }
 
+// ---- input conditioning of the reducer thread (mod.rs:351-478, dynamics.rs:152-360) ----
+// Sample-sequential IIRs and a per-slot tracker with sorts: host work in the reference and here
+// (one stream has no parallelism to offer a GPU); it supplies what the detectors need from outside
+// the path - conditioned samples and noise_floor_db per slot.
+#pragma clang fp contract(off)
+namespace {
+struct Biquad {
+    float b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0, x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    void design(float sample_rate, float freq, bool lowpass)
+    {
+        const float w0 = 2.0f * 3.14159265358979323846f * freq / sample_rate;
+        const float cw = std::cos(w0), sw = std::sin(w0);
+        const float alpha = sw / (2.0f * 0.707f);
+        const float nb0 = lowpass ? (1.0f - cw) / 2.0f : (1.0f + cw) / 2.0f;
+        const float nb1 = lowpass ? 1.0f - cw : -(1.0f + cw);
+        const float a0 = 1.0f + alpha;
+        b0 = nb0 / a0;
+        b1 = nb1 / a0;
+        b2 = nb0 / a0;
+        a1 = (-2.0f * cw) / a0;
+        a2 = (1.0f - alpha) / a0;
+    }
+    float step(float x)
+    {
+        const float y = b0 * x + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
+        x2 = x1;
+        x1 = x;
+        y2 = y1;
+        y1 = y;
+        return y;
+    }
+};
+float to_db(float linear) { return 20.0f * std::log10(std::max(linear, 1e-9f)); }
+}  // namespace
+
+struct aa_conditioner {
+    int slot_len = 1024;
+    Biquad hp, lp;
+    float gate_threshold = 0, envelope = 0, release = 0;
+    int64_t hold_samples = 0, hold_left = 0;
+    // DynamicsTracker
+    std::vector<float> quiet_rms = std::vector<float>(256, 0.0f), playing_rms = std::vector<float>(5000, 0.0f);
+    std::vector<float> sorted;
+    size_t quiet_pos = 0, playing_pos = 0;
+    bool quiet_full = false, playing_full = false;
+    float gain = 1.0f, target_db = -18.0f, max_boost_db = 100.0f, smooth_alpha = 0, silence_alpha = 0;
+    float active_snr_db = 20.0f, bootstrap_floor_db = -55.0f;
+};
+
+int aa_conditioner_create(float sample_rate, int32_t slot_len, aa_conditioner **out)
+{
+    if (!out || !(sample_rate > 0.0f) || slot_len < 1)
+        return fail(AA_ERR_ARG, "aa_conditioner_create: bad argument");
+    aa_conditioner *c = new (std::nothrow) aa_conditioner();
+    if (!c)
+        return fail(AA_ERR_NOMEM, "aa_conditioner_create: out of memory");
+    c->slot_len = slot_len;
+    c->hp.design(sample_rate, 40.0f, false);
+    c->lp.design(sample_rate, 14000.0f, true);
+    c->gate_threshold = std::pow(10.0f, -60.0f / 20.0f);
+    c->release = std::exp(-1.0f / (0.040f * sample_rate));
+    c->hold_samples = (int64_t)(0.020f * sample_rate);
+    const float slot_rate = sample_rate / (float)slot_len;
+    c->smooth_alpha = 1.0f - std::exp(-1.0f / (240.0f * slot_rate));
+    c->silence_alpha = 1.0f - std::exp(-1.0f / (10.0f * slot_rate));
+    *out = c;
+    return AA_OK;
+}
+
+int aa_conditioner_destroy(aa_conditioner *c)
+{
+    delete c;
+    return AA_OK;
+}
+
+int aa_conditioner_process(aa_conditioner *c, float *samples_host, int64_t n_slots, float *noise_floor_db,
+                           float *rms_db_out, float *gain_db, float *session_median_db, int32_t *level)
+{
+    if (!c || !samples_host || n_slots < 0 || !noise_floor_db || !rms_db_out || !gain_db || !session_median_db ||
+        !level)
+        return fail(AA_ERR_ARG, "aa_conditioner_process: bad argument");
+    const int n = c->slot_len;
+    for (int64_t s = 0; s < n_slots; ++s) {
+        float *slot = samples_host + s * (int64_t)n;
+        // 40 Hz high-pass, 14 kHz low-pass, envelope gate (instant attack, 40 ms release, 20 ms hold)
+        for (int i = 0; i < n; ++i) {
+            const float x = c->lp.step(c->hp.step(slot[i]));
+            const float mag = std::fabs(x);
+            if (mag > c->envelope) {
+                c->envelope = mag;
+                c->hold_left = c->hold_samples;
+            } else {
+                c->envelope = c->release * c->envelope + (1.0f - c->release) * mag;
+            }
+            float g = 1.0f;
+            if (c->envelope < c->gate_threshold) {
+                if (c->hold_left > 0) {
+                    c->hold_left -= 1;
+                } else {
+                    const float ratio = c->envelope / c->gate_threshold;
+                    g = ratio * ratio * ratio * ratio;
+                }
+            }
+            slot[i] = x * g;
+        }
+        // slot loudness and the noise floor = 10th percentile of the quiet slots' RMS
+        float sum_sq = 0.0f;
+        for (int i = 0; i < n; ++i)
+            sum_sq += slot[i] * slot[i];
+        const float rms = std::sqrt(sum_sq / (float)n);
+        const float rms_db = to_db(rms);
+        const size_t quiet_n = c->quiet_full ? c->quiet_rms.size() : std::max<size_t>(c->quiet_pos, 1);
+        c->sorted.assign(c->quiet_rms.begin(), c->quiet_rms.begin() + quiet_n);
+        std::sort(c->sorted.begin(), c->sorted.end());
+        const float floor_now_db = to_db(std::max(c->sorted[(size_t)((float)(quiet_n - 1) * 0.10f)], 1e-9f));
+        const float gate_floor_db = quiet_n >= 32 ? floor_now_db : c->bootstrap_floor_db;
+        const bool active = rms_db > gate_floor_db + c->active_snr_db;
+        bool broadband = false;
+        if (active) {   // Gaussian-like kurtosis at a low level = ambient noise, not playing
+            const float mean_sq = rms * rms;
+            float quad = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const float s2 = slot[i] * slot[i];
+                quad += s2 * s2;
+            }
+            const float mean_quad = quad / (float)n;
+            const float kurt = mean_sq > 1e-18f ? mean_quad / (mean_sq * mean_sq) : 3.0f;
+            broadband = kurt >= 2.75f && kurt <= 3.8f && rms_db < -45.0f;
+        }
+        const bool playing = active && !broadband;
+        if (!active || broadband) {
+            c->quiet_rms[c->quiet_pos] = rms;
+            c->quiet_pos = (c->quiet_pos + 1) % c->quiet_rms.size();
+            c->quiet_full = c->quiet_full || c->quiet_pos == 0;
+        }
+        if (playing) {
+            c->playing_rms[c->playing_pos] = rms;
+            c->playing_pos = (c->playing_pos + 1) % c->playing_rms.size();
+            c->playing_full = c->playing_full || c->playing_pos == 0;
+        }
+        // session statistics: median and 95th percentile of the playing slots
+        const size_t play_n = c->playing_full ? c->playing_rms.size() : c->playing_pos;
+        float want_gain_db = 0.0f, median_db = rms_db;
+        if (play_n > 0) {
+            c->sorted.assign(c->playing_rms.begin(), c->playing_rms.begin() + play_n);
+            std::sort(c->sorted.begin(), c->sorted.end());
+            median_db = to_db(std::max(c->sorted[(play_n - 1) / 2], 1e-9f));
+            const float p95_db = to_db(std::max(c->sorted[(size_t)((float)(play_n - 1) * 0.95f)], 1e-9f));
+            want_gain_db = std::min(std::max(c->target_db - p95_db, 0.0f), c->max_boost_db);
+        }
+        if (playing)
+            c->gain += c->smooth_alpha * (std::pow(10.0f, want_gain_db / 20.0f) - c->gain);
+        else
+            c->gain += c->silence_alpha * (1.0f - c->gain);
+        float peak = 0.0f;
+        for (int i = 0; i < n; ++i)
+            peak = std::max(peak, std::fabs(slot[i]));
+        const float applied = std::min(c->gain, 0.97f / std::max(peak, 1e-9f));
+        for (int i = 0; i < n; ++i)
+            slot[i] *= applied;
+        int32_t lv = 0;   // Silence, then Ppp .. Fff by level relative to the session median
+        if (playing) {
+            const float rel = rms_db - median_db;
+            static const float edges[7] = {-15.0f, -9.0f, -4.5f, -1.5f, 1.5f, 4.5f, 9.0f};
+            lv = 1;
+            for (float e : edges)
+                lv += rel < e ? 0 : 1;
+        }
+        noise_floor_db[s] = floor_now_db;
+        rms_db_out[s] = rms_db;
+        gain_db[s] = to_db(applied);
+        session_median_db[s] = median_db;
+        level[s] = lv;
+    }
+    return AA_OK;
+}
+
 // PitchTracker (src/audio_io/stft.rs:28-117): sequential hit / miss hysteresis over <= 8 raw
 // pitches per frame - host logic, like in the reference (nothing here is worth a kernel).
 struct aa_pitch_tracker {

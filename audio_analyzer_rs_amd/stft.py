@@ -263,6 +263,46 @@ def tuner_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0, s
     return freq, score, count
 
 
+class Conditioner:
+    """Mirror of the reducer thread's conditioning (src/audio_io/mod.rs:351-478 + DynamicsTracker,
+    dynamics.rs): biquads, gate, AGC per slot, on the host.  process() takes whole slots (numpy
+    float32), returns the conditioned samples and the per-slot DynamicsOutput arrays."""
+
+    def __init__(self, sample_rate=48000.0, slot_len=1024):
+        self._lib = _lib.load()
+        self.slot_len = int(slot_len)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.aa_conditioner_create(float(sample_rate), self.slot_len, ctypes.byref(h)))
+        self._h = h
+
+    def process(self, samples):
+        x = np.array(samples, dtype=np.float32)
+        n_slots = len(x) // self.slot_len
+        x = x[: n_slots * self.slot_len].copy()
+        out = {"noise_floor_db": np.empty(n_slots, np.float32), "rms_db": np.empty(n_slots, np.float32),
+               "gain_db": np.empty(n_slots, np.float32), "session_median_db": np.empty(n_slots, np.float32),
+               "level": np.empty(n_slots, np.int32)}
+        _lib.check(self._lib.aa_conditioner_process(
+            self._h, x.ctypes.data, n_slots, out["noise_floor_db"].ctypes.data, out["rms_db"].ctypes.data,
+            out["gain_db"].ctypes.data, out["session_median_db"].ctypes.data, out["level"].ctypes.data))
+        return x, out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.aa_conditioner_destroy(self._h)
+            self._h = None
+
+
+def global_floor_per_frame(noise_floor_db, n_frames, n_fft, hop, n_bins, slot_len=1024):
+    """global_floor[t] = 10^(noise_floor_db / 20) * n_bins / 2 (stft.rs:322-324, onset.rs:299-300)
+    with the value of the slot that holds frame t's last sample - the latest one the reference's
+    worker can have read when it processes that frame.  float32 numpy [n_frames]."""
+    nf_db = np.asarray(noise_floor_db, dtype=np.float32)
+    last = (np.arange(n_frames, dtype=np.int64) * hop + n_fft - 1) // slot_len
+    last = np.minimum(last, len(nf_db) - 1)
+    return (np.float32(10.0) ** (nf_db[last] / np.float32(20.0)) * np.float32(n_bins) / np.float32(2.0)).astype(np.float32)
+
+
 class PitchTracker:
     """Mirror of the reference's PitchTracker (src/audio_io/stft.rs:28-117): feed it the per-frame
     raw pitches of tuner_pitches (numpy arrays on the host), get the stable pitches back."""

@@ -6,7 +6,10 @@
 // src/analysis/onset.rs) on the GPU and prints JSON:
 //   {"sample_rate":..,"frames":..,"onsets":[{"beat_position":..,"raw_sample_offset":..,"velocity":..},..],
 //    "notes":[{"frame":..,"pitches":[[freq,score],..]},..]}
-// Usage: aa_analyze <file.wav> [bpm=120] [noise_floor_db=-60] [note_stride=50]
+// The samples first pass the reducer thread's conditioning (aa_conditioner_*: biquads, gate, AGC;
+// audio_io/mod.rs:351-478), which also yields noise_floor_db per 1024-sample slot - the
+// detectors' global_floor - exactly as the live engine feeds its workers.
+// Usage: aa_analyze <file.wav> [bpm=120] [note_stride=50]
 // Build: make -C audio_analyzer_rs_amd/csrc examples
 #include <hip/hip_runtime.h>
 
@@ -88,18 +91,39 @@ static bool read_wav(const char *path, std::vector<float> *out, int *sample_rate
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: %s file.wav [bpm=120] [noise_floor_db=-60] [note_stride=50]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s file.wav [bpm=120] [note_stride=50]\n", argv[0]);
         return 1;
     }
     const double bpm = argc > 2 ? std::atof(argv[2]) : 120.0;
-    const float noise_floor_db = argc > 3 ? (float)std::atof(argv[3]) : -60.0f;
-    const int note_stride = argc > 4 ? std::atoi(argv[4]) : 50;
+    const int note_stride = argc > 3 ? std::atoi(argv[3]) : 50;
     std::vector<float> x;
     int sr = 0;
     if (!read_wav(argv[1], &x, &sr)) {
         std::fprintf(stderr, "%s: not a 16-bit PCM WAV file\n", argv[1]);
         return 1;
     }
+    // ---- conditioning: whole 1024-sample slots, in place; noise floor per slot ----
+    const int slot_len = 1024;
+    const int64_t n_slots = (int64_t)x.size() / slot_len;
+    x.resize((size_t)(n_slots * slot_len));
+    std::vector<float> nf_db((size_t)std::max<int64_t>(n_slots, 1), -60.0f), rms_db(nf_db.size()), gain_db(nf_db.size()),
+        med_db(nf_db.size());
+    std::vector<int32_t> level(nf_db.size());
+    aa_conditioner *cond = nullptr;
+    CHECK_AA(aa_conditioner_create((float)sr, slot_len, &cond));
+    CHECK_AA(aa_conditioner_process(cond, x.data(), n_slots, nf_db.data(), rms_db.data(), gain_db.data(),
+                                    med_db.data(), level.data()));
+    aa_conditioner_destroy(cond);
+    // global_floor of frame t: the slot holding its last sample (stft.rs:322-324, onset.rs:299-300)
+    auto global_floor = [&](int64_t frames, int n_fft, int hop, int n_bins) {
+        std::vector<float> gf((size_t)frames);
+        for (int64_t t = 0; t < frames; ++t) {
+            int64_t slot = (t * hop + n_fft - 1) / slot_len;
+            slot = std::min<int64_t>(slot, n_slots - 1);
+            gf[(size_t)t] = std::pow(10.0f, nf_db[(size_t)slot] / 20.0f) * (float)n_bins / 2.0f;
+        }
+        return gf;
+    };
     const int64_t n = (int64_t)x.size();
     float *d_x = nullptr;
     CHECK_HIP(hipMalloc(&d_x, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
@@ -130,8 +154,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMalloc(&d_freq, sizeof(float) * (size_t)tf * 8));
         CHECK_HIP(hipMalloc(&d_score, sizeof(float) * (size_t)tf * 8));
         CHECK_HIP(hipMalloc(&d_count, sizeof(int32_t) * (size_t)tf));
-        // global_floor = 10^(noise_floor_db / 20) * half_size / 2 (stft.rs:322-324), constant here
-        std::vector<float> gf((size_t)tf, std::pow(10.0f, noise_floor_db / 20.0f) * (float)tb / 2.0f);
+        std::vector<float> gf = global_floor(tf, 2048, 512, tb);
         CHECK_HIP(hipMemcpy(d_gf, gf.data(), sizeof(float) * (size_t)tf, hipMemcpyHostToDevice));
         CHECK_AA(aa_stft_execute_device(tuner, d_x, n, 0, tf, d_mag, nullptr));
         CHECK_AA(aa_tuner_floor_device(d_mag, tf, tb, d_gf, d_state, 0, d_eff, nullptr));
@@ -170,7 +193,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMalloc(&d_state, sizeof(float) * (size_t)(ob + 3)));
         CHECK_HIP(hipMalloc(&d_cnt, sizeof(int32_t) * (size_t)of));
         CHECK_HIP(hipMalloc(&d_flags, (size_t)of));
-        std::vector<float> gf((size_t)of, std::pow(10.0f, noise_floor_db / 20.0f) * (float)ob / 2.0f);
+        std::vector<float> gf = global_floor(of, 256, 64, ob);
         CHECK_HIP(hipMemcpy(d_gf, gf.data(), sizeof(float) * (size_t)of, hipMemcpyHostToDevice));
         CHECK_AA(aa_stft_execute_device(onset, d_x, n, 0, of, d_mag, nullptr));
         CHECK_AA(aa_onset_flux_device(d_mag, of, ob, nullptr, d_flux, d_energy, nullptr));

@@ -263,6 +263,23 @@ int aa_tuner_floor_batch_device(const float *mags_dev, const int64_t *frame_offs
                                 float *state_dev, const int32_t *initialized_dev, float *eff_floor_dev,
                                 void *stream);
 
+/* ---- input conditioning of the reducer thread (audio_io/mod.rs:351-478, dynamics.rs:152-360), host ---- */
+/* The step before the path ("next" row f-3): per 1024-sample slot a 40 Hz high-pass and a 14 kHz
+ * low-pass biquad (Q 0.707), an envelope gate (-60 dB, 40 ms release, 20 ms hold, ratio^4) and the
+ * DynamicsTracker (slot RMS; noise floor = 10th percentile of the quiet slots; active / broadband
+ * classification; median and 95th percentile of the playing slots; AGC towards -18 dB with a
+ * 240 s time constant and a 0.97 peak clamp; dynamic level).  Sample-sequential IIRs and per-slot
+ * sorts: host work, as in the reference.  It produces the two things the detectors take from
+ * outside the path: the conditioned samples and noise_floor_db per slot, from which
+ * global_floor = 10^(noise_floor_db / 20) * n_bins / 2 (stft.rs:322-324, onset.rs:299-300).
+ * samples_host: n_slots * slot_len samples, processed in place.  Per-slot outputs as the
+ * reference's DynamicsOutput (dynamics.rs:340-347); level: 0 = Silence, 1..8 = Ppp..Fff. */
+typedef struct aa_conditioner aa_conditioner;
+int aa_conditioner_create(float sample_rate, int32_t slot_len, aa_conditioner **out);
+int aa_conditioner_destroy(aa_conditioner *c);
+int aa_conditioner_process(aa_conditioner *c, float *samples_host, int64_t n_slots, float *noise_floor_db,
+                           float *rms_db, float *gain_db, float *session_median_db, int32_t *level);
+
 /* ---- tuner: PitchTracker hysteresis (src/audio_io/stft.rs:28-117), host side ---- */
 /* Sequential over frames and tiny (<= 8 raw pitches per frame): host logic as in the reference.
  * A raw pitch within 3 % of an unmatched track updates it (EMA 0.6 / 0.4, or a snap when the

@@ -12,6 +12,7 @@ which cannot be built in this image.  The oracle is pinned against a float64
 from .capi import (  # noqa: F401
     Oracle,
     build_oracle,
+    condition,
     extract_pitches,
     hann_window,
     num_frames,

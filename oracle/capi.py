@@ -73,6 +73,13 @@ class Oracle:
                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, _f32p, _f32p,
                                           ctypes.POINTER(ctypes.c_int32)]
         lib.aao_pitch_tracker.restype = None
+        lib.aao_conditioner_create.argtypes = [ctypes.c_float, ctypes.c_int]
+        lib.aao_conditioner_create.restype = ctypes.c_void_p
+        lib.aao_conditioner_destroy.argtypes = [ctypes.c_void_p]
+        lib.aao_conditioner_destroy.restype = None
+        lib.aao_conditioner_process.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, _f32p,
+                                                ctypes.POINTER(ctypes.c_int32)]
+        lib.aao_conditioner_process.restype = None
         lib.aao_tuner_floor.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_int), _f32p]
         lib.aao_tuner_floor.restype = None
@@ -274,3 +281,30 @@ def pitch_tracker(freq, score, count, onset=None, cap=32):
         None if on is None else on.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), nf, _ptr(tracks),
         ctypes.byref(n_tracks), cap, _ptr(of), _ptr(os_), oc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     return of, os_, oc
+
+
+def condition(samples, sample_rate=48000.0, slot_len=1024, pieces=None):
+    """Reducer-thread conditioning (src/audio_io/mod.rs:351-478 + dynamics.rs:152-360) of whole slots.
+    pieces: optional list of slot counts to feed in separate calls (state carried).
+    Returns (conditioned samples, dict of per-slot arrays)."""
+    x = np.array(samples, dtype=np.float32)
+    n_slots = len(x) // slot_len
+    x = x[: n_slots * slot_len].copy()
+    out = {"noise_floor_db": np.empty(n_slots, np.float32), "rms_db": np.empty(n_slots, np.float32),
+           "gain_db": np.empty(n_slots, np.float32), "session_median_db": np.empty(n_slots, np.float32),
+           "level": np.empty(n_slots, np.int32)}
+    lib = Oracle.get().lib
+    c = lib.aao_conditioner_create(sample_rate, slot_len)
+    try:
+        done = 0
+        for cnt in (pieces or [n_slots]):
+            sl = slice(done, done + cnt)
+            seg = x[done * slot_len:(done + cnt) * slot_len]
+            args = [out[k][sl] for k in ("noise_floor_db", "rms_db", "gain_db", "session_median_db")]
+            lv = out["level"][sl]
+            lib.aao_conditioner_process(c, _ptr(seg), cnt, *[_ptr(a) for a in args],
+                                        lv.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+            done += cnt
+    finally:
+        lib.aao_conditioner_destroy(c)
+    return x, out

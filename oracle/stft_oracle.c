@@ -828,6 +828,202 @@ void aao_pitch_tracker(const float *freq, const float *score, const int32_t *cou
     free(matched);
 }
 
+/* ---------------------------------- input conditioning (reducer thread) -- */
+
+/* The step before the path ("next" row f-3): what the reducer thread does to every 1024-sample slot
+ * before the STFT workers see it (src/audio_io/mod.rs:351-478): 40 Hz high-pass and 14 kHz low-pass
+ * biquads (Q 0.707), envelope gate (-60 dB threshold, 40 ms release, 20 ms hold, ratio^4), then
+ * DynamicsTracker::process_slot (src/audio_io/dynamics.rs:152-360; constructed mod.rs:341-349 with
+ * target -18 dB, max boost 100 dB, smoothing 240 s): slot RMS, noise floor = p10 of the quiet
+ * slots' RMS (256 history), active / broadband (kurtosis) classification, p50 / p95 of the
+ * playing slots' RMS (5000 history), smoothed AGC gain with a 0.97 peak clamp, dynamic level.
+ * Plain f32 in the reference's order; libm for cos / sin / exp / pow / log10 / sqrt. */
+typedef struct {
+    float hp[5], lp[5];                 /* b0 b1 b2 a1 a2 (normalised by a0) */
+    float hp_x1, hp_x2, hp_y1, hp_y2, lp_x1, lp_x2, lp_y1, lp_y2;
+    float gate_threshold_linear, envelope, release_coeff;
+    int64_t gate_hold_samples, gate_hold_remaining;
+    int slot_len;
+    float long_history[256], play_history[5000], sort_buf[5000];
+    int long_pos, long_filled, play_pos, play_filled;
+    float current_gain_linear, target_db, max_boost_db, smooth_alpha, silence_decay_alpha;
+    float active_snr_db, bootstrap_floor_db;
+} aao_conditioner;
+
+static void aao_biquad(float sample_rate, float freq, int is_lpf, float *c)
+{
+    const float w0 = 2.0f * 3.14159265358979323846f * freq / sample_rate;
+    const float cos_w0 = cosf(w0), sin_w0 = sinf(w0);
+    const float alpha = sin_w0 / (2.0f * 0.707f);
+    float b0, b1, b2;
+    if (is_lpf) {
+        b0 = (1.0f - cos_w0) / 2.0f;
+        b1 = 1.0f - cos_w0;
+        b2 = (1.0f - cos_w0) / 2.0f;
+    } else {
+        b0 = (1.0f + cos_w0) / 2.0f;
+        b1 = -(1.0f + cos_w0);
+        b2 = (1.0f + cos_w0) / 2.0f;
+    }
+    const float a0 = 1.0f + alpha, a1 = -2.0f * cos_w0, a2 = 1.0f - alpha;
+    c[0] = b0 / a0;
+    c[1] = b1 / a0;
+    c[2] = b2 / a0;
+    c[3] = a1 / a0;
+    c[4] = a2 / a0;
+}
+static float aao_linear_to_db(float l) { return 20.0f * log10f(fmaxf(l, 1e-9f)); }
+static int aao_cmp_f32(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+void *aao_conditioner_create(float sample_rate, int slot_len)
+{
+    aao_conditioner *c = (aao_conditioner *)calloc(1, sizeof *c);
+    if (!c)
+        return NULL;
+    aao_biquad(sample_rate, 40.0f, 0, c->hp);
+    aao_biquad(sample_rate, 14000.0f, 1, c->lp);
+    c->gate_threshold_linear = powf(10.0f, -60.0f / 20.0f);
+    c->release_coeff = expf(-1.0f / (0.040f * sample_rate));
+    c->gate_hold_samples = (int64_t)(0.020f * sample_rate);
+    c->slot_len = slot_len;
+    const float slot_rate = sample_rate / (float)slot_len;
+    c->current_gain_linear = 1.0f;
+    c->target_db = -18.0f;
+    c->max_boost_db = 100.0f;
+    c->smooth_alpha = 1.0f - expf(-1.0f / (240.0f * slot_rate));
+    c->silence_decay_alpha = 1.0f - expf(-1.0f / (10.0f * slot_rate));
+    c->active_snr_db = 20.0f;
+    c->bootstrap_floor_db = -55.0f;
+    return c;
+}
+void aao_conditioner_destroy(void *p) { free(p); }
+
+/* n_slots slots of slot_len samples, in place; per-slot outputs as DynamicsOutput (dynamics.rs:340-347):
+ * level 0 = Silence, 1..8 = Ppp..Fff. */
+void aao_conditioner_process(void *p, float *samples, int64_t n_slots, float *noise_floor_db_out,
+                             float *rms_db_out, float *gain_db_out, float *median_db_out, int32_t *level_out)
+{
+    aao_conditioner *c = (aao_conditioner *)p;
+    const int n = c->slot_len;
+    for (int64_t s = 0; s < n_slots; ++s) {
+        float *slot = samples + s * (int64_t)n;
+        for (int i = 0; i < n; ++i) {
+            float x = slot[i];
+            const float hp_out = c->hp[0] * x + c->hp[1] * c->hp_x1 + c->hp[2] * c->hp_x2 - c->hp[3] * c->hp_y1 -
+                                 c->hp[4] * c->hp_y2;
+            c->hp_x2 = c->hp_x1;
+            c->hp_x1 = x;
+            c->hp_y2 = c->hp_y1;
+            c->hp_y1 = hp_out;
+            x = hp_out;
+            const float lp_out = c->lp[0] * x + c->lp[1] * c->lp_x1 + c->lp[2] * c->lp_x2 - c->lp[3] * c->lp_y1 -
+                                 c->lp[4] * c->lp_y2;
+            c->lp_x2 = c->lp_x1;
+            c->lp_x1 = x;
+            c->lp_y2 = c->lp_y1;
+            c->lp_y1 = lp_out;
+            x = lp_out;
+            const float abs_in = fabsf(x);
+            if (abs_in > c->envelope) {
+                c->envelope = abs_in;
+                c->gate_hold_remaining = c->gate_hold_samples;
+            } else {
+                c->envelope = c->release_coeff * c->envelope + (1.0f - c->release_coeff) * abs_in;
+            }
+            float gain;
+            if (c->envelope >= c->gate_threshold_linear) {
+                gain = 1.0f;
+            } else if (c->gate_hold_remaining > 0) {
+                c->gate_hold_remaining -= 1;
+                gain = 1.0f;
+            } else {
+                const float ratio = c->envelope / c->gate_threshold_linear;
+                gain = ratio * ratio * ratio * ratio;
+            }
+            slot[i] = x * gain;
+        }
+        /* ---- DynamicsTracker::process_slot ---- */
+        float sum_sq = 0.0f;
+        for (int i = 0; i < n; ++i)
+            sum_sq += slot[i] * slot[i];
+        const float rms_linear = sqrtf(sum_sq / (float)n);
+        const float rms_db = aao_linear_to_db(rms_linear);
+        const int long_n = c->long_filled ? 256 : (c->long_pos > 1 ? c->long_pos : 1);
+        memcpy(c->sort_buf, c->long_history, sizeof(float) * (size_t)long_n);
+        qsort(c->sort_buf, (size_t)long_n, sizeof(float), aao_cmp_f32);
+        const int p10_idx = (int)((float)(long_n - 1) * 0.10f);
+        const float noise_floor_db = aao_linear_to_db(fmaxf(c->sort_buf[p10_idx], 1e-9f));
+        const float floor_db = long_n >= 32 ? noise_floor_db : c->bootstrap_floor_db;
+        const int is_active = rms_db > floor_db + c->active_snr_db;
+        int is_broadband = 0;
+        if (is_active) {
+            const float mean_sq = rms_linear * rms_linear;
+            float quad = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const float s2 = slot[i] * slot[i];
+                quad += s2 * s2;
+            }
+            const float mean_quad = quad / (float)n;
+            const float kurtosis = mean_sq > 1e-18f ? mean_quad / (mean_sq * mean_sq) : 3.0f;
+            is_broadband = kurtosis >= 2.75f && kurtosis <= 3.8f && rms_db < -45.0f;
+        }
+        const int is_playing = is_active && !is_broadband;
+        if (!is_active || is_broadband) {
+            c->long_history[c->long_pos] = rms_linear;
+            c->long_pos = (c->long_pos + 1) % 256;
+            if (c->long_pos == 0)
+                c->long_filled = 1;
+        }
+        if (is_playing) {
+            c->play_history[c->play_pos] = rms_linear;
+            c->play_pos = (c->play_pos + 1) % 5000;
+            if (c->play_pos == 0)
+                c->play_filled = 1;
+        }
+        const int play_n = c->play_filled ? 5000 : c->play_pos;
+        float raw_gain_db = 0.0f, session_median_db = rms_db;
+        if (play_n > 0) {
+            memcpy(c->sort_buf, c->play_history, sizeof(float) * (size_t)play_n);
+            qsort(c->sort_buf, (size_t)play_n, sizeof(float), aao_cmp_f32);
+            const int p50_idx = (play_n - 1) / 2;
+            const int p95_idx = (int)((float)(play_n - 1) * 0.95f);
+            session_median_db = aao_linear_to_db(fmaxf(c->sort_buf[p50_idx], 1e-9f));
+            const float p95_db = aao_linear_to_db(fmaxf(c->sort_buf[p95_idx], 1e-9f));
+            float g = c->target_db - p95_db;
+            raw_gain_db = g < 0.0f ? 0.0f : (g > c->max_boost_db ? c->max_boost_db : g);
+        }
+        if (is_playing) {
+            const float target_linear = powf(10.0f, raw_gain_db / 20.0f);
+            c->current_gain_linear += c->smooth_alpha * (target_linear - c->current_gain_linear);
+        } else {
+            c->current_gain_linear += c->silence_decay_alpha * (1.0f - c->current_gain_linear);
+        }
+        float peak = 0.0f;
+        for (int i = 0; i < n; ++i)
+            peak = fmaxf(peak, fabsf(slot[i]));
+        peak = fmaxf(peak, 1e-9f);
+        const float headroom_limit = 0.97f / peak;
+        const float effective_gain = fminf(c->current_gain_linear, headroom_limit);
+        for (int i = 0; i < n; ++i)
+            slot[i] *= effective_gain;
+        int32_t level = 0;
+        if (is_playing) {
+            const float r = rms_db - session_median_db;
+            level = r < -15.0f ? 1 : r < -9.0f ? 2 : r < -4.5f ? 3 : r < -1.5f ? 4 : r < 1.5f ? 5 : r < 4.5f ? 6
+                                                                                                 : r < 9.0f ? 7 : 8;
+        }
+        noise_floor_db_out[s] = noise_floor_db;
+        rms_db_out[s] = rms_db;
+        gain_db_out[s] = aao_linear_to_db(effective_gain);
+        median_db_out[s] = session_median_db;
+        level_out[s] = level;
+    }
+}
+
 /* ------------------------------------------------------ synthetic signals -- */
 
 /* LCG of the reference's metronome noise tick (src/generators/metronome.rs:56-57):

@@ -486,13 +486,14 @@ def test_cpp_example_host_program(aa, torch_mod, tmp_path):
     x = (0.6 * _chord_signal(seconds=2.0, seed=5) + _burst_signal(seconds=2.0, seed=6)).astype(np.float32)
     wav = tmp_path / "session.wav"
     aa.wav.write_wav(wav, x, sr)
-    res = json.loads(subprocess.check_output([exe, str(wav), "90", "-60", "10"], timeout=120).decode())
+    res = json.loads(subprocess.check_output([exe, str(wav), "90", "10"], timeout=120).decode())
     y, _ = aa.wav.read_wav(wav)
+    y, dyn = aa.Conditioner(sr).process(y)                                  # biquads, gate, AGC; noise floor per slot
     yd = torch_mod.from_numpy(y).cuda()
     # onsets
     om = aa.Stft(256, 64, output="mag")(yd)
     flux, energy = aa.onset_flux(om)
-    gf = torch_mod.full((om.shape[0],), float(np.float32(10.0) ** np.float32(-60.0 / 20.0) * np.float32(129) / 2), device="cuda")
+    gf = torch_mod.from_numpy(aa.global_floor_per_frame(dyn["noise_floor_db"], om.shape[0], 256, 64, 129)).cuda()
     gates, _ = aa.onset_gates(om, flux, energy, gf)
     fired = np.nonzero((gates["flags"].cpu().numpy() & 16) > 0)[0]
     assert len(res["onsets"]) == len(fired) >= 2
@@ -503,7 +504,7 @@ def test_cpp_example_host_program(aa, torch_mod, tmp_path):
     # notes
     tm = aa.Stft(2048, 512, output="mag")(yd)
     nb = tm.shape[1]
-    tgf = torch_mod.full((tm.shape[0],), float(np.float32(10.0) ** np.float32(-60.0 / 20.0) * np.float32(nb) / 2), device="cuda")
+    tgf = torch_mod.from_numpy(aa.global_floor_per_frame(dyn["noise_floor_db"], tm.shape[0], 2048, 512, nb)).cuda()
     eff, _ = aa.tuner_floor(tm, tgf)
     fr, sc, cnt = aa.tuner_pitches(tm, eff, sr / 2048)
     sf, ss, scnt = aa.PitchTracker().process(fr.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy())

@@ -219,6 +219,33 @@ def test_pitch_tracker_host_matches_restatement(oracle_mod):
     assert np.all(np.abs(rf[150:, 0][rc[150:] > 0] / 220.0 - 1.0) < 0.02)
 
 
+def test_conditioner_host_matches_restatement(oracle_mod):
+    """ "next" row f-3: the reducer thread's conditioning (mod.rs:351-478) and DynamicsTracker
+    (dynamics.rs:152-360) - sample-sequential host logic in the reference and in the product
+    (aa_conditioner_*, no GPU involved).  Product C++ vs the C restatement: bit-exact, also when fed
+    in pieces; and the behaviour itself: gate, noise floor, AGC clamp, levels."""
+    import audio_analyzer_rs_amd as aa
+
+    rng = np.random.default_rng(2)
+    x = np.concatenate([_burst_signal(seconds=12.0, seed=1), 0.5 * _chord_signal(seconds=8.0),
+                        (3e-4 * rng.standard_normal(48000 * 12)).astype(np.float32)]).astype(np.float32)
+    y, o = oracle_mod.condition(x)
+    c = aa.Conditioner()
+    y1, o1 = c.process(x[: 300 * 1024])
+    y2, o2 = c.process(x[300 * 1024:])
+    assert np.array_equal(np.concatenate([y1, y2]), y)
+    for k in o:
+        assert np.array_equal(np.concatenate([o1[k], o2[k]]), o[k]), k
+    yp, op = oracle_mod.condition(x, pieces=[100, len(y) // 1024 - 100])
+    assert np.array_equal(yp, y) and all(np.array_equal(op[k], o[k]) for k in o)
+    assert np.abs(y).max() <= 0.97 + 1e-6                                   # peak-headroom clamp
+    assert o["level"].min() == 0 and o["level"].max() >= 6                  # silence .. forte
+    assert o["noise_floor_db"][0] == np.float32(-180.0)                     # empty history: 20 log10(1e-9)
+    assert -80.0 < o["noise_floor_db"][-1] < -65.0                          # settles on the 3e-4 noise
+    gf = aa.global_floor_per_frame(o["noise_floor_db"], 10, 2048, 512, 1025)
+    assert gf.dtype == np.float32 and gf[0] == np.float32(10.0) ** (o["noise_floor_db"][1] / np.float32(20.0)) * np.float32(512.5)
+
+
 def test_tuner_floor_restatement(oracle_mod):
     # stft.rs:326-367 — first frame initialises, a steady loud bin freezes, quiet bins release
     nb = 4
