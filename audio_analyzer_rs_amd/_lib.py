@@ -64,6 +64,22 @@ class StftConfig(ctypes.Structure):
     ]
 
 
+class TunerOutputStruct(ctypes.Structure):
+    """Mirror of `aa_tuner_output` (include/aa_stft.h)."""
+
+    _fields_ = [
+        ("label", ctypes.c_char * 256),
+        ("cents", ctypes.c_float),
+        ("n_notes", ctypes.c_int32),
+        ("notes", (ctypes.c_char * 8) * 32),
+        ("accuracies", ctypes.c_float * 32),
+        ("mode", ctypes.c_int32),
+        ("system", ctypes.c_int32),
+        ("base_freq", ctypes.c_float),
+        ("beat_position", ctypes.c_double),
+    ]
+
+
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
@@ -125,6 +141,15 @@ SIGNATURES = {
                                                 ctypes.c_void_p]),
     "aa_tuner_floor_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_note_from_freq": (ctypes.c_int, [ctypes.c_float, ctypes.c_float, ctypes.c_char_p, _f32p]),
+    "aa_note_to_freq": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_float, ctypes.c_float, _f32p]),
+    "aa_midi_from_freq": (ctypes.c_int, [ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_int32), _f32p]),
+    "aa_midi_to_freq": (ctypes.c_int, [ctypes.c_int32, ctypes.c_float, ctypes.c_float, _f32p]),
+    "aa_interval": (ctypes.c_int, [_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, _f32p]),
+    "aa_tuner_output_build": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_float, ctypes.c_double, ctypes.POINTER(TunerOutputStruct)]),
+    "aa_tuner_output_json": (ctypes.c_int, [ctypes.POINTER(TunerOutputStruct), ctypes.c_char_p, ctypes.c_char_p,
+                                            ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "aa_shard_frames": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]),
     "aa_shard_samples": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.c_int32, _i64p, _i64p]),

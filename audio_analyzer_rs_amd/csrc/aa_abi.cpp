@@ -13,10 +13,11 @@
 #include <vector>
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char *fmt, ...)
+// records the message aa_last_error() returns (shared with aa_theory.cpp) and hands the code back
+int aa::abi_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -24,6 +25,9 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+#define fail(...) aa::abi_fail(__VA_ARGS__)
+
+namespace {
 
 #define AA_HIP(expr)                                                                         \
     do {                                                                                     \

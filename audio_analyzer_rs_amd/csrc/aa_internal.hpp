@@ -7,6 +7,9 @@
 
 namespace aa {
 
+// Sets the calling thread's aa_last_error() text and returns `code` (defined in aa_abi.cpp).
+int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
 // Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
 // the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
 enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5 };

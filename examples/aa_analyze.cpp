@@ -232,7 +232,21 @@ int main(int argc, char **argv)
                           st_freq[(size_t)t * AA_PITCH_TRACKS_MAX + i], st_score[(size_t)t * AA_PITCH_TRACKS_MAX + i]);
             js += item;
         }
-        js += "]}";
+        js += "]";
+        // what Tuner::poll_output would have shown after this frame (tuner.rs:141-207, lib.rs:80-82)
+        aa_tuner_output tout;
+        const int64_t centre = t * 512 + 1024;
+        CHECK_AA(aa_tuner_output_build(&st_freq[(size_t)t * AA_PITCH_TRACKS_MAX], &st_score[(size_t)t * AA_PITCH_TRACKS_MAX],
+                                       st_count[(size_t)t], AA_TUNER_MULTI_PITCH, AA_TUNING_EQUAL_TEMPERAMENT, 440.0f,
+                                       (double)centre / sr * bpm / 60.0, &tout));
+        if (tout.n_notes > 0) {
+            char tj[2048];
+            size_t tl = 0;
+            CHECK_AA(aa_tuner_output_json(&tout, "C major", tj, sizeof tj, &tl));
+            js += ",\"tuner\":";
+            js += tj;
+        }
+        js += "}";
         first = false;
     }
     js += "]}";

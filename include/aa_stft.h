@@ -295,6 +295,59 @@ int aa_pitch_tracker_process(aa_pitch_tracker *t, const float *freq_host, const 
                              const int32_t *count_host, const uint8_t *onset_host, int64_t n_frames,
                              float *out_freq_host, float *out_score_host, int32_t *out_count_host);
 
+/* ---- tuner: TunerOutput - note / interval naming and the polled JSON (host) ---- */
+/* What the reference's tuner thread makes of each stable pitch list ("next" row f-4, the JSON side):
+ * src/analysis/theory.rs (Note, MidiNote, Interval) and the body of Tuner::run
+ * (src/analysis/tuner.rs:141-207); Tuner::poll_output (src/lib.rs:80-82) serialises the result with
+ * serde_json.  A few scalar f32 operations per frame: host code, as in the reference.  This is the
+ * one stage the reference pins with known-answer tests (theory.rs:404-627); tests/test_theory.py
+ * restates them against these entry points.
+ * base_freq is the A4 reference (the reference's `Option<f32>` None = 440.0). */
+#define AA_NOTE_NAME_LEN 8
+#define AA_TUNER_NOTES_MAX 32
+enum { AA_TUNER_MULTI_PITCH = 0, AA_TUNER_SINGLE_PITCH = 1 };                         /* tuner.rs:20-25 */
+enum { AA_TUNING_EQUAL_TEMPERAMENT = 0, AA_TUNING_JUST_INTONATION = 1, AA_TUNING_PYTHAGOREAN = 2 }; /* :12-18 */
+
+/* Note::from_freq + get_name + get_cents (theory.rs:199-254): nearest equal-tempered pitch, sharps
+ * only ("A4", "C#5"), and the offset from it in cents. */
+int aa_note_from_freq(float freq, float base_freq, char name[AA_NOTE_NAME_LEN], float *cents);
+/* Note::try_new + to_freq (theory.rs:104-197): letter, optional accidental (# b x B n), octave 0..255;
+ * cents is the Note's offset (0 for a parsed name, get_cents() for one made by from_freq).
+ * A name that does not parse is AA_ERR_ARG with the reason in aa_last_error (the reference: Err). */
+int aa_note_to_freq(const char *name, float cents, float base_freq, float *freq);
+/* MidiNote::from_freq / to_freq (theory.rs:16-28, 40-43); midi is a u8 there (0..255). */
+int aa_midi_from_freq(float freq, float base_freq, int32_t *midi, float *cents);
+int aa_midi_to_freq(int32_t midi, float cents, float base_freq, float *freq);
+/* Interval::new + get_name + get_accuracy (theory.rs:289-381): freqs[1] / freqs[0] folded into
+ * (0, 2], nearest of the 13 ratios of the tuning system -> "Per8" "Min2" ... "Maj7", accuracy =
+ * -ln(nearest / ratio) * 1732.5.  n < 2 or freqs[0] == 0 gives "Per8" / 0 as there.  An infinite
+ * ratio is AA_ERR_ARG (the reference's folding loop would not terminate). */
+int aa_interval(const float *freqs, int32_t n, int32_t system, char name[AA_NOTE_NAME_LEN], float *accuracy);
+
+/* `struct TunerOutput` (tuner.rs:38-56) without the key string, which the caller owns. */
+typedef struct aa_tuner_output {
+    char label[256];                                      /* "C#4", "Per5", or the note names joined by spaces */
+    float cents;
+    int32_t n_notes;                                      /* 0: empty pitch list - the reference keeps its previous output */
+    char notes[AA_TUNER_NOTES_MAX][AA_NOTE_NAME_LEN];
+    float accuracies[AA_TUNER_NOTES_MAX];
+    int32_t mode, system;
+    float base_freq;
+    double beat_position;
+} aa_tuner_output;
+/* One pass of the tuner loop (tuner.rs:153-207) over one frame's stable pitches (a row of
+ * aa_pitch_tracker_process's output, n = its count): one pitch or SinglePitch mode -> the note of
+ * the highest score (the last of equal scores); two -> sorted, the interval names the label and
+ * its accuracy the cents; three or more -> the note names joined.  base_freq is clamped to
+ * [220, 880] as TunerCommand::SetBaseFreq does (tuner.rs:119). */
+int aa_tuner_output_build(const float *freq_host, const float *score_host, int32_t n, int32_t mode,
+                          int32_t system, float base_freq, double beat_position, aa_tuner_output *out);
+/* The string Tuner::poll_output returns: {"label":..,"cents":..,"notes":[..],"accuracies":[..],
+ * "mode":"MultiPitch","system":"EqualTemperament","base_freq":440.0,"key":"C major",
+ * "beat_position":..}, floats in serde_json's shortest round-trip form.  *len receives the length
+ * without the terminator; AA_ERR_LEN when cap is too small (len is still set). */
+int aa_tuner_output_json(const aa_tuner_output *out, const char *key, char *buf, size_t cap, size_t *len);
+
 /* ---- frame-range sharding (one rank per GPU) --------------- */
 /* Rank r of `world` owns frames [floor(r*F/world), floor((r+1)*F/world)) and needs
  * samples [f0*hop, (f1-1)*hop + n_fft) — a halo of n_fft-hop samples shared with

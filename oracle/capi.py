@@ -16,9 +16,9 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 
 
 def build_oracle(force=False):
-    """Compile oracle/stft_oracle.c with the committed Makefile (gcc)."""
-    src = os.path.join(_HERE, "stft_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    """Compile oracle/stft_oracle.c + theory_oracle.c with the committed Makefile (gcc)."""
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("stft_oracle.c", "theory_oracle.c"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _SO
 
@@ -85,6 +85,21 @@ class Oracle:
         lib.aao_tuner_floor.restype = None
         lib.aao_lcg_next.argtypes = [ctypes.c_uint32]
         lib.aao_lcg_next.restype = ctypes.c_uint32
+        # theory_oracle.c
+        lib.aao_note_from_freq.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_char_p, _f32p]
+        lib.aao_note_from_freq.restype = None
+        lib.aao_note_to_freq.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_float, _f32p]
+        lib.aao_note_to_freq.restype = ctypes.c_int
+        lib.aao_midi_from_freq.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_int32), _f32p]
+        lib.aao_midi_from_freq.restype = None
+        lib.aao_midi_to_freq.argtypes = [ctypes.c_int32, ctypes.c_float, ctypes.c_float]
+        lib.aao_midi_to_freq.restype = ctypes.c_float
+        lib.aao_interval.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, _f32p]
+        lib.aao_interval.restype = None
+        lib.aao_tuner_output.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                         ctypes.c_char_p, _f32p, ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p,
+                                         _f32p]
+        lib.aao_tuner_output.restype = None
         self.lib = lib
 
     @classmethod
@@ -308,3 +323,57 @@ def condition(samples, sample_rate=48000.0, slot_len=1024, pieces=None):
     finally:
         lib.aao_conditioner_destroy(c)
     return x, out
+
+
+# ---- theory_oracle.c: note / interval naming and the TunerOutput assembly ----
+
+def note_from_freq(freq, base_freq=440.0):
+    """Note::from_freq (src/analysis/theory.rs:199-232) -> (name, cents as np.float32)."""
+    name = ctypes.create_string_buffer(8)
+    cents = ctypes.c_float()
+    Oracle.get().lib.aao_note_from_freq(freq, base_freq, name, ctypes.byref(cents))
+    return name.value.decode(), np.float32(cents.value)
+
+
+def note_to_freq(name, base_freq=440.0, cents=0.0):
+    """Note::try_new + to_freq (theory.rs:104-197); None when the name does not parse."""
+    f = ctypes.c_float()
+    rc = Oracle.get().lib.aao_note_to_freq(name.encode(), cents, base_freq, ctypes.byref(f))
+    return None if rc else np.float32(f.value)
+
+
+def midi_from_freq(freq, base_freq=440.0):
+    midi = ctypes.c_int32()
+    cents = ctypes.c_float()
+    Oracle.get().lib.aao_midi_from_freq(freq, base_freq, ctypes.byref(midi), ctypes.byref(cents))
+    return midi.value, np.float32(cents.value)
+
+
+def midi_to_freq(midi, cents=0.0, base_freq=440.0):
+    return np.float32(Oracle.get().lib.aao_midi_to_freq(midi, cents, base_freq))
+
+
+def interval(freqs, system=0):
+    """Interval::new (theory.rs:289-381) -> (name, accuracy)."""
+    f = np.ascontiguousarray(freqs, dtype=np.float32)
+    name = ctypes.create_string_buffer(8)
+    acc = ctypes.c_float()
+    Oracle.get().lib.aao_interval(_ptr(f) if len(f) else None, len(f), system, name, ctypes.byref(acc))
+    return name.value.decode(), np.float32(acc.value)
+
+
+def tuner_output(freqs, scores, mode=0, system=0, base_freq=440.0):
+    """Body of Tuner::run for one non-empty pitch list (src/analysis/tuner.rs:153-193)."""
+    f = np.ascontiguousarray(freqs, dtype=np.float32)
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    label = ctypes.create_string_buffer(512)
+    names = ctypes.create_string_buffer(8 * 32)
+    acc = np.zeros(32, np.float32)
+    cents = ctypes.c_float()
+    n = ctypes.c_int32()
+    Oracle.get().lib.aao_tuner_output(_ptr(f), _ptr(s), len(f), mode, system, base_freq, label, ctypes.byref(cents),
+                                      ctypes.byref(n), names, _ptr(acc))
+    raw = names.raw
+    return {"label": label.value.decode(), "cents": np.float32(cents.value),
+            "notes": [raw[8 * i:8 * i + 8].split(b"\0")[0].decode() for i in range(n.value)],
+            "accuracies": acc[:n.value].copy()}

@@ -515,7 +515,17 @@ def test_cpp_example_host_program(aa, torch_mod, tmp_path):
         assert len(n["pitches"]) == scnt[t]
         for (f, s_), rf, rs in zip(n["pitches"], sf[t], ss[t]):
             assert abs(f - rf) < 2e-3 and abs(s_ - rs) < 2e-4
+        # the TunerOutput JSON of that frame (tuner.rs:141-207), against the Python mirror of the same entry points
+        if scnt[t] == 0:
+            assert "tuner" not in n
+            continue
+        tuner = aa.Tuner()
+        want = json.loads(tuner.update(sf[t, :scnt[t]], ss[t, :scnt[t]], (t * 512 + 1024) / sr * 90 / 60).to_json())
+        assert n["tuner"] == want
+        assert len(n["tuner"]["notes"]) == scnt[t] and n["tuner"]["key"] == "C major"
     assert max(len(n["pitches"]) for n in res["notes"]) >= 2
+    # the chord signal is A major-ish: the note names are real pitch names
+    assert any(set(n.get("tuner", {}).get("notes", [])) & {"A3", "A4", "C#4", "C#5", "E4", "E5"} for n in res["notes"])
 
 
 def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
