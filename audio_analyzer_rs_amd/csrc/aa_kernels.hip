@@ -537,6 +537,31 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
     __builtin_amdgcn_wave_barrier();
 }
 
+// The SIMD's instruction arbiter serves waves by priority, then age.  With equal priorities the
+// workgroups that share a CU do not progress together: they finish one after the other in dispatch
+// order (measured: 38 / 50 / 62 / 73 us for the four residents of every CU,
+// tools/ablate_w1024.hip), the oldest wave of each SIMD runs nearly unimpeded and the others take
+// the leftover issue slots.  Rotating the priority by (dispatch round + a step that advances four
+// times per chunk) hands every resident the head of the queue in turn: -3 % on the sustained
+// 1024 / 256 launch.  Once per chunk gives -2.6 %, eight times per chunk nothing (the branches cut
+// the interleaved phases apart); a static youngest-first order, a progress-based priority and a
+// dynamic chunk queue were measured too (tools/experiments/) and lost.
+// step is uniform across the workgroup; only the issue order changes, never a result.
+#ifndef AA_PRIO_ROTATE
+#define AA_PRIO_ROTATE 1      // 0: diagnostic builds without the rotation (tools/ab_sustained.py)
+#endif
+__device__ __forceinline__ void rotate_wave_priority(int step)
+{
+    if (!AA_PRIO_ROTATE)
+        return;
+    switch (step & 3) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
+
 // ---------------------------------------------------- wave-per-frame, n_fft = 1024 --
 // One wavefront transforms one frame: the 1024 windowed reals are read as 512 complex points
 // z[m] (8 per lane), 512 = 8 x 8 x 8:
@@ -557,7 +582,8 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 // packed f32 (pk_* helpers above).  ABL is the ablation mask of tools/ablate_w1024.hip (0 in the
 // shipped library): 1 no stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split
 // strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines,
-// 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80).
+// 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80), 1024 no
+// priority rotation.
 template <int OUT, int ABL = 0, bool WIDE = false>
 __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
@@ -647,6 +673,9 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        const int prio_step = (int)(blockIdx.x >> 8) + 4 * (c - c0);   // dispatch round + quarter chunks
+        if (!(ABL & 1024))
+            rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         if (c + 1 < c1 && !(ABL & 8)) {
             const int nleft = frames_left - frames_per_wg;
@@ -834,12 +863,18 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 pass_a(va);
                 exchange1(va);
+                if (!(ABL & 1024))
+                    rotate_wave_priority(prio_step + 1);
                 pass_a(vbv);
                 exchange1(vbv);
+                if (!(ABL & 1024))
+                    rotate_wave_priority(prio_step + 2);
                 pass_bc(va);
                 strip(va, pa);
                 pass_bc(vbv);
                 strip(vbv, pb);
+                if (!(ABL & 1024))
+                    rotate_wave_priority(prio_step + 3);
                 epilogue(va, pa, ta, true, 0);
                 epilogue(vbv, pb, tb, vb, 1);
                 if (OUT == kLogMel) {
@@ -999,6 +1034,8 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // 4 dwordx4 pieces + head/tail dwords
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        const int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority
+        rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
@@ -1020,6 +1057,7 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             fft512_exchange1(e, e1_wr, e1_rd);
             fft512_pass_a(o, twA);
             fft512_exchange1(o, e1_wr, e1_rd);
+            rotate_wave_priority(prio_step + 1);
             fft512_pass_bc(e, twB);
             fft512_pass_bc(o, twB);
             // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
@@ -1260,6 +1298,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority; + 1 per group
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
@@ -1268,6 +1307,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * qA);
 
         for (int g = wave; FPW * g < nf; g += 4) {
+            rotate_wave_priority(prio_step++);
             const int t = FPW * g + fqA;               // this lane's frame within the chunk
             const int nvalid = nf - FPW * g < FPW ? nf - FPW * g : FPW;
             // a lane of a frame past the end reads the last valid frame instead (stays in the

@@ -1,0 +1,46 @@
+"""A/B of library builds under the sustained (power-limited) regime of bench.py: each build runs in
+its own process, alternating, one launch (default: the headline 1024/256 magnitudes of 10 min;
+AB_NFFT / AB_HOP / AB_OUT select another geometry) back to back.
+Usage: python tools/ab_sustained.py libA.so libB.so [libC.so ...] [rounds]   (diagnostic, not shipped)"""
+import os
+import subprocess
+import sys
+
+CHILD = r"""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+import audio_analyzer_rs_amd as aa
+aa._lib.LIB_PATH = os.path.abspath(sys.argv[1])
+x = aa.signals.synth_corpus(0, 28_800_000)
+xd = torch.from_numpy(x).cuda()
+n_fft, hop, kind = int(os.environ.get("AB_NFFT", "1024")), int(os.environ.get("AB_HOP", "256")), os.environ.get("AB_OUT", "mag")
+extra = dict(n_mels=128) if kind in ("logmel", "mfcc") else {}
+if kind == "mfcc":
+    extra["n_mfcc"] = 40
+plan = aa.Stft(n_fft, hop, output=kind, **extra)
+nf = plan.num_frames(xd.shape[0])
+out = torch.empty((nf, plan.cols), dtype=torch.float32, device="cuda")
+st = torch.cuda.current_stream()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.4:
+    for _ in range(50):
+        plan.execute_device(xd, 0, nf, out=out, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+res = []
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(1000):
+        plan.execute_device(xd, 0, nf, out=out, stream=st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize()
+    res.append(e0.elapsed_time(e1))
+print(" ".join("%.2f" % r for r in res))
+"""
+
+libs = [a for a in sys.argv[1:] if not a.isdigit()]
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
+for r in range(rounds):
+    for lib in libs:
+        out = subprocess.check_output([sys.executable, "-c", CHILD, lib]).decode().strip().splitlines()[-1]
+        print(f"round {r} {os.path.basename(lib):32s} us/step: {out}", flush=True)

@@ -6,6 +6,8 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#include <string>
+#include <cstdlib>
 
 static float *dx, *dout, *dtab;
 static unsigned *dcnt;
@@ -45,6 +47,10 @@ double run(int fpw, const char *name, int force_per_cu = 0)
         life.push_back(clk[4 * b + 1] * 0.01);
         start.push_back((clk[4 * b + 2] - first) * 0.01);
         endt.push_back((clk[4 * b + 2] - first + clk[4 * b + 1]) * 0.01);
+    }
+    if (const char *dump = getenv("AA_CLK_DUMP")) {      // raw per-workgroup records of the last launch of this run
+        std::string path = std::string(dump) + "_" + std::to_string(ABL) + "_" + std::to_string(per_cu) + ".bin";
+        if (FILE *f = fopen(path.c_str(), "wb")) { fwrite(clk.data(), 8, 4 * (size_t)nb, f); fclose(f); }
     }
     std::sort(life.begin(), life.end()); std::sort(endt.begin(), endt.end());
     printf("fpw %2d  %-40s %d WG/CU  median %.2f us  min %.2f us | WG life min/med/max %.1f/%.1f/%.1f  end p10/p50/p90/max %.1f/%.1f/%.1f/%.1f\n",
@@ -88,7 +94,10 @@ int main(int argc, char **argv)
     run<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)");
     run<512>(fpw, "E2 through LDS instead of registers");
     run<512 | 1>(fpw, "E2 through LDS, no global stores");
+    run<1024>(fpw, "no priority rotation (residents finish in dispatch order)");
+    run<1024 | 1>(fpw, "no priority rotation, no global stores");
     run<0>(fpw, "full kernel (again)");
+    run<1024>(fpw, "no priority rotation (again)");
     run<512>(fpw, "E2 through LDS (again)");
     return 0;
 }
