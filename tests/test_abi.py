@@ -37,6 +37,31 @@ def test_header_symbols_are_exported(lib):
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_header_is_plain_c_and_structs_match_the_ctypes_mirrors(tmp_path):
+    """include/aa_stft.h is a C header (the Rust / cgo / ctypes bindings read it as such): it compiles
+    as C99 with no warnings, and the two structs that cross the boundary have the layout the Python
+    mirror (and the #[repr(C)] structs of INTEGRATION.md) assume."""
+    import subprocess
+
+    from audio_analyzer_rs_amd import _lib
+
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include "aa_stft.h"\n#include <stddef.h>\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(aa_stft_config), sizeof(aa_tuner_output),\n'
+        "         offsetof(aa_tuner_output, cents), offsetof(aa_tuner_output, notes), offsetof(aa_tuner_output, accuracies),\n"
+        "         offsetof(aa_tuner_output, base_freq), offsetof(aa_tuner_output, beat_position));\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    T = _lib.TunerOutputStruct
+    assert got == [ctypes.sizeof(_lib.StftConfig), ctypes.sizeof(T), T.cents.offset, T.notes.offset,
+                   T.accuracies.offset, T.base_freq.offset, T.beat_position.offset]
+
+
 def test_abi_version_and_error_string(lib):
     assert lib.aa_abi_version() == 1
     assert isinstance(lib.aa_last_error(), bytes)
