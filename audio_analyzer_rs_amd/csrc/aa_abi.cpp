@@ -1258,16 +1258,39 @@ struct Biquad {
 float to_db(float linear) { return 20.0f * std::log10(std::max(linear, 1e-9f)); }
 }  // namespace
 
+// A ring of the last N slot levels together with the same values in ascending order.  The
+// reference copies and sorts the window every slot (dynamics.rs:211-217, 291-301: 5000 values, ~0.1 ms
+// - nothing at 47 slots a second, 4.5 of the 5.2 s an offline pass over ten minutes took here); an
+// order statistic depends on the multiset only, so the sorted copy is kept current by one erase and
+// one insert instead: the same percentiles, bit for bit.
+struct SortedRing {
+    std::vector<float> ring, sorted;
+    size_t pos = 0;
+    bool full = false;
+    explicit SortedRing(size_t n) : ring(n, 0.0f) { sorted.reserve(n); }
+    size_t count() const { return sorted.size(); }
+    void push(float v)
+    {
+        if (full) {
+            auto old = std::lower_bound(sorted.begin(), sorted.end(), ring[pos]);
+            if (old != sorted.end())
+                sorted.erase(old);
+        }
+        ring[pos] = v;
+        sorted.insert(std::upper_bound(sorted.begin(), sorted.end(), v), v);
+        pos = (pos + 1) % ring.size();
+        full = full || pos == 0;
+    }
+};
+
 struct aa_conditioner {
     int slot_len = 1024;
     Biquad hp, lp;
     float gate_threshold = 0, envelope = 0, release = 0;
     int64_t hold_samples = 0, hold_left = 0;
-    // DynamicsTracker
-    std::vector<float> quiet_rms = std::vector<float>(256, 0.0f), playing_rms = std::vector<float>(5000, 0.0f);
-    std::vector<float> sorted;
-    size_t quiet_pos = 0, playing_pos = 0;
-    bool quiet_full = false, playing_full = false;
+    // DynamicsTracker: 256 quiet slots (~12 s) for the noise floor, 5000 playing slots (~8 min) for the
+    // session median and the AGC target
+    SortedRing quiet{256}, playing{5000};
     float gain = 1.0f, target_db = -18.0f, max_boost_db = 100.0f, smooth_alpha = 0, silence_alpha = 0;
     float active_snr_db = 20.0f, bootstrap_floor_db = -55.0f;
 };
@@ -1334,10 +1357,10 @@ int aa_conditioner_process(aa_conditioner *c, float *samples_host, int64_t n_slo
             sum_sq += slot[i] * slot[i];
         const float rms = std::sqrt(sum_sq / (float)n);
         const float rms_db = to_db(rms);
-        const size_t quiet_n = c->quiet_full ? c->quiet_rms.size() : std::max<size_t>(c->quiet_pos, 1);
-        c->sorted.assign(c->quiet_rms.begin(), c->quiet_rms.begin() + quiet_n);
-        std::sort(c->sorted.begin(), c->sorted.end());
-        const float floor_now_db = to_db(std::max(c->sorted[(size_t)((float)(quiet_n - 1) * 0.10f)], 1e-9f));
+        // (an empty history reads as its first, still zero, element: dynamics.rs:204-217)
+        const size_t quiet_n = std::max<size_t>(c->quiet.count(), 1);
+        const float p10 = c->quiet.count() ? c->quiet.sorted[(size_t)((float)(quiet_n - 1) * 0.10f)] : 0.0f;
+        const float floor_now_db = to_db(std::max(p10, 1e-9f));
         const float gate_floor_db = quiet_n >= 32 ? floor_now_db : c->bootstrap_floor_db;
         const bool active = rms_db > gate_floor_db + c->active_snr_db;
         bool broadband = false;
@@ -1353,24 +1376,17 @@ int aa_conditioner_process(aa_conditioner *c, float *samples_host, int64_t n_slo
             broadband = kurt >= 2.75f && kurt <= 3.8f && rms_db < -45.0f;
         }
         const bool playing = active && !broadband;
-        if (!active || broadband) {
-            c->quiet_rms[c->quiet_pos] = rms;
-            c->quiet_pos = (c->quiet_pos + 1) % c->quiet_rms.size();
-            c->quiet_full = c->quiet_full || c->quiet_pos == 0;
-        }
-        if (playing) {
-            c->playing_rms[c->playing_pos] = rms;
-            c->playing_pos = (c->playing_pos + 1) % c->playing_rms.size();
-            c->playing_full = c->playing_full || c->playing_pos == 0;
-        }
+        if (!active || broadband)
+            c->quiet.push(rms);
+        if (playing)
+            c->playing.push(rms);
         // session statistics: median and 95th percentile of the playing slots
-        const size_t play_n = c->playing_full ? c->playing_rms.size() : c->playing_pos;
+        const size_t play_n = c->playing.count();
         float want_gain_db = 0.0f, median_db = rms_db;
         if (play_n > 0) {
-            c->sorted.assign(c->playing_rms.begin(), c->playing_rms.begin() + play_n);
-            std::sort(c->sorted.begin(), c->sorted.end());
-            median_db = to_db(std::max(c->sorted[(play_n - 1) / 2], 1e-9f));
-            const float p95_db = to_db(std::max(c->sorted[(size_t)((float)(play_n - 1) * 0.95f)], 1e-9f));
+            const std::vector<float> &sorted = c->playing.sorted;
+            median_db = to_db(std::max(sorted[(play_n - 1) / 2], 1e-9f));
+            const float p95_db = to_db(std::max(sorted[(size_t)((float)(play_n - 1) * 0.95f)], 1e-9f));
             want_gain_db = std::min(std::max(c->target_db - p95_db, 0.0f), c->max_boost_db);
         }
         if (playing)

@@ -13,6 +13,7 @@
 // Build: make -C audio_analyzer_rs_amd/csrc examples
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -88,8 +89,22 @@ static bool read_wav(const char *path, std::vector<float> *out, int *sample_rate
     return false;
 }
 
+// wall-clock phase marks on stderr when AA_ANALYZE_TIMING is set
+struct PhaseClock {
+    bool on = std::getenv("AA_ANALYZE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (on)
+            std::fprintf(stderr, "%-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int main(int argc, char **argv)
 {
+    PhaseClock phase;
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s file.wav [bpm=120] [note_stride=50]\n", argv[0]);
         return 1;
@@ -102,6 +117,7 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "%s: not a 16-bit PCM WAV file\n", argv[1]);
         return 1;
     }
+    phase.mark("read wav");
     // ---- conditioning: whole 1024-sample slots, in place; noise floor per slot ----
     const int slot_len = 1024;
     const int64_t n_slots = (int64_t)x.size() / slot_len;
@@ -114,6 +130,7 @@ int main(int argc, char **argv)
     CHECK_AA(aa_conditioner_process(cond, x.data(), n_slots, nf_db.data(), rms_db.data(), gain_db.data(),
                                     med_db.data(), level.data()));
     aa_conditioner_destroy(cond);
+    phase.mark("conditioner (host)");
     // global_floor of frame t: the slot holding its last sample (stft.rs:322-324, onset.rs:299-300)
     auto global_floor = [&](int64_t frames, int n_fft, int hop, int n_bins) {
         std::vector<float> gf((size_t)frames);
@@ -128,6 +145,7 @@ int main(int argc, char **argv)
     float *d_x = nullptr;
     CHECK_HIP(hipMalloc(&d_x, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
     CHECK_HIP(hipMemcpy(d_x, x.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    phase.mark("HIP init + upload");
 
     // ---- tuner chain: 2048 / 512 (stft.rs:169-170) ----
     aa_stft_config cfg{};
@@ -173,6 +191,7 @@ int main(int argc, char **argv)
             (void)hipFree(p);
     }
     aa_stft_plan_destroy(tuner);
+    phase.mark("tuner chain");
 
     // ---- onset chain: 256 / 64 (onset.rs:122-123) ----
     cfg.n_fft = 256;
@@ -208,6 +227,7 @@ int main(int argc, char **argv)
     aa_stft_plan_destroy(onset);
     (void)hipFree(d_x);
 
+    phase.mark("onset chain");
     // ---- JSON ----
     std::string js = "{\"sample_rate\":" + std::to_string(sr) + ",\"frames\":" + std::to_string(tf) + ",\"onsets\":[";
     bool first = true;
@@ -251,5 +271,6 @@ int main(int argc, char **argv)
     }
     js += "]}";
     std::puts(js.c_str());
+    phase.mark("JSON");
     return 0;
 }

@@ -246,6 +246,31 @@ def test_conditioner_host_matches_restatement(oracle_mod):
     assert gf.dtype == np.float32 and gf[0] == np.float32(10.0) ** (o["noise_floor_db"][1] / np.float32(20.0)) * np.float32(512.5)
 
 
+def test_conditioner_long_session_wraps_both_histories(oracle_mod):
+    """The play history holds 5000 playing slots (dynamics.rs:166-177) and the quiet history 256: a
+    session long enough to wrap both (the product keeps the windows sorted incrementally, the
+    restatement sorts them every slot as the reference does - same percentiles, bit for bit)."""
+    import audio_analyzer_rs_amd as aa
+
+    rng = np.random.default_rng(11)
+    sr, n_play = 48000, 5600 * 1024
+    t = np.arange(n_play, dtype=np.float64) / sr
+    loud = 0.05 + 0.25 * (0.5 + 0.5 * np.sin(2 * np.pi * t / 7.3))          # level wanders over the session
+    play = (loud * np.sin(2 * np.pi * 330.0 * t) + 0.3 * loud * np.sin(2 * np.pi * 660.0 * t)).astype(np.float32)
+    quiet = (2e-4 * rng.standard_normal(300 * 1024)).astype(np.float32)
+    x = np.concatenate([quiet, play, quiet, play[: 800 * 1024]])
+    y, o = oracle_mod.condition(x)
+    c = aa.Conditioner()
+    cut = 2900 * 1024
+    y1, o1 = c.process(x[:cut])
+    y2, o2 = c.process(x[cut:])
+    assert np.array_equal(np.concatenate([y1, y2]), y)
+    for k in o:
+        assert np.array_equal(np.concatenate([o1[k], o2[k]]), o[k]), k
+    assert (o["level"] > 0).sum() > 5000 + 600                               # the play window wrapped
+    assert (o["level"] == 0).sum() > 2 * 256                                 # and the quiet one
+
+
 def test_tuner_floor_restatement(oracle_mod):
     # stft.rs:326-367 — first frame initialises, a steady loud bin freezes, quiet bins release
     nb = 4
