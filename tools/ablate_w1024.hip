@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <string>
 #include <cstdlib>
+#include <ctime>
 
 static float *dx, *dout, *dtab;
 static unsigned *dcnt;
@@ -58,6 +59,39 @@ double run(int fpw, const char *name, int force_per_cu = 0)
     return ts[ts.size() / 2];
 }
 
+// AA_ABL_SUSTAIN=<seconds>: every variant back to back for that long, the rate measured over the
+// last third, with wall-clock marks so that a rocm-smi sampler running beside (tools/power_by_variant.sh)
+// can be lined up: which part of the kernel the package power goes to.
+template <int ABL>
+void sustain(int fpw, const char *name, double seconds)
+{
+    const int64_t chunks = (n_frames + fpw - 1) / fpw;
+    const size_t lds = aa::wave1024_lds_bytes(fpw, hop);
+    int per_cu = 1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_kernel<aa::kMag, ABL, true>, 256, lds);
+    const int grid = 256 * per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    const double t_begin = ts.tv_sec + 1e-9 * ts.tv_nsec;
+    double now = t_begin, last_us = 0;
+    while (now - t_begin < seconds) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 500; ++i)
+            hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched());
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        last_us = ms * 2.0;     // per launch
+        clock_gettime(CLOCK_REALTIME, &ts);
+        now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
+    printf("SUSTAIN %-44s begin %.2f end %.2f  last %.2f us/launch\n", name, t_begin, now, last_us);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
     const int fpw = argc > 1 ? atoi(argv[1]) : 8;
@@ -81,6 +115,19 @@ int main(int argc, char **argv)
     hipMemcpy(dx, hx.data(), n_samples * 4, hipMemcpyHostToDevice);
     hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < 8; ++i) run<0>(fpw, "warm-up (ignore)");
+    if (const char *sus = getenv("AA_ABL_SUSTAIN")) {
+        const double sec = atof(sus);
+        sustain<0>(fpw, "full kernel", sec);
+        sustain<1>(fpw, "no global stores", sec);
+        sustain<256>(fpw, "stores hit 32 L2-resident rows", sec);
+        sustain<8>(fpw, "no DMA after first chunk", sec);
+        sustain<2 | 4 | 16>(fpw, "no exchanges at all", sec);
+        sustain<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier", sec);
+        sustain<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)", sec);
+        sustain<1024>(fpw, "no priority rotation", sec);
+        sustain<0>(fpw, "full kernel (again)", sec);
+        return 0;
+    }
     for (int pc : {2, 3, 4, 5}) run<0>(fpw, "full kernel", pc);
     run<1>(fpw, "no global stores");
     run<256>(fpw, "stores hit 32 L2-resident rows");
