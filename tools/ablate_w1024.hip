@@ -62,13 +62,13 @@ double run(int fpw, const char *name, int force_per_cu = 0)
 // AA_ABL_SUSTAIN=<seconds>: every variant back to back for that long, the rate measured over the
 // last third, with wall-clock marks so that a rocm-smi sampler running beside (tools/power_by_variant.sh)
 // can be lined up: which part of the kernel the package power goes to.
-template <int ABL>
+template <int ABL, bool WIDE = true>
 void sustain(int fpw, const char *name, double seconds)
 {
     const int64_t chunks = (n_frames + fpw - 1) / fpw;
     const size_t lds = aa::wave1024_lds_bytes(fpw, hop);
     int per_cu = 1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_kernel<aa::kMag, ABL, true>, 256, lds);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, aa::stft_wave1024_kernel<aa::kMag, ABL, WIDE>, 256, lds);
     const int grid = 256 * per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,7 +79,7 @@ void sustain(int fpw, const char *name, double seconds)
     while (now - t_begin < seconds) {
         hipEventRecord(e0, 0);
         for (int i = 0; i < 500; ++i)
-            hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
+            hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, WIDE>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
                                (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched());
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
@@ -125,6 +125,7 @@ int main(int argc, char **argv)
         sustain<1 | 8 | 32>(fpw, "no stores, no DMA, no barrier", sec);
         sustain<1 | 2 | 4 | 8 | 16 | 32>(fpw, "math only (+frame LDS reads)", sec);
         sustain<1024>(fpw, "no priority rotation", sec);
+        sustain<0, false>(fpw, "rows stored from registers (9 dword stores)", sec);
         sustain<0>(fpw, "full kernel (again)", sec);
         return 0;
     }
