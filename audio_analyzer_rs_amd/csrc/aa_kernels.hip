@@ -67,6 +67,16 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w)
 }
 
 template <int OUT>
+__device__ __forceinline__ float bin_from_power(float p, float log_floor)
+{
+    if (OUT == kMag)
+        return __builtin_amdgcn_sqrtf(p);
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR)
+        return p;
+    return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
+}
+
+template <int OUT>
 __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
 {
     float p = re * re + im * im;
@@ -110,6 +120,31 @@ __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)  // a - conj(b)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The two halves of pk_cmul for loops that want every multiply ahead of every dependent FMA (a
+// dependent pair back to back costs a wait state: the hazard recogniser puts an s_nop between them).
+__device__ __forceinline__ v2f pk_cmul_lo(v2f a, v2f w)
+{
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+}
+__device__ __forceinline__ v2f pk_cmul_hi(v2f a, v2f w, v2f t)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// v[1..7] *= w[1..7]
+__device__ __forceinline__ void pk_twiddle7(v2f (&v)[8], const v2f (&w)[8])
+{
+    v2f t[8];
+#pragma unroll
+    for (int kk = 1; kk < 8; ++kk)
+        t[kk] = pk_cmul_lo(v[kk], w[kk]);
+#pragma unroll
+    for (int kk = 1; kk < 8; ++kk)
+        v[kk] = pk_cmul_hi(v[kk], w[kk], t[kk]);
+}
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)      // a * w
 {
     v2f t, r;
@@ -143,12 +178,14 @@ __device__ __forceinline__ void pk_dft8(v2f (&v)[8])
     v2f a1 = v[1] + v[5], b1 = v[1] - v[5];
     v2f a2 = v[2] + v[6], b2 = v[2] - v[6];
     v2f a3 = v[3] + v[7], b3 = v[3] - v[7];
+    // (statement order: no operation reads the result of the one just before it - a dependent
+    // packed pair back to back costs a wait state)
     const v2f p = pk_add_mi(b1, b1);                 // (x + y, y - x)
     const v2f q = pk_add_pi(b3, b3);                 // (x - y, x + y)
-    const v2f e = p - q, g = p + q;                  // d1 = h e, w = h g
     v2f c0 = a0 + a2, c2 = a0 - a2;
     v2f c1 = a1 + a3, u = a1 - a3;                   // c3 = -i u
     v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);   // b0 +- (-i b2)
+    const v2f e = p - q, g = p + q;                  // d1 = h e, w = h g
     v[0] = c0 + c1; v[4] = c0 - c1;
     v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
     v[1] = d0 + e * hp; v[5] = d0 - e * hp;
@@ -696,9 +733,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
             for (int j = 0; j < 8; ++j)
                 v[j] = v[j] * win[j];
             pk_dft8(v);
-#pragma unroll
-            for (int kk = 1; kk < 8; ++kk)
-                v[kk] = pk_cmul(v[kk], twA[kk]);
+            pk_twiddle7(v, twA);
         };
         auto exchange1 = [&](v2f (&v)[8]) {           // E1 through LDS
             if (ABL & 4)
@@ -717,9 +752,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
         };
         auto pass_bc = [&](v2f (&v)[8]) {
             pk_dft8(v);
-#pragma unroll
-            for (int kk = 1; kk < 8; ++kk)
-                v[kk] = pk_cmul(v[kk], twB[kk]);
+            pk_twiddle7(v, twB);
             if (ABL & 512) {
                 // E2 through LDS as well (variant timed by tools/ablate_w1024.hip): writer as E1,
                 // reader lane (k1 = L & 7, ka = L >> 3) takes 8 consecutive complex from 66 k1 + 8 ka
@@ -762,13 +795,24 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
             // ABL 256: all rows land in the first 32 rows of `out` (L2-resident): same store
             // instructions, no HBM write stream
             float *row = (ABL & 256) ? out + ((row0 + t) & 31) * COLS : out_chunk + t * COLS;
-            v2f xk[4], xm[4];
+            // stage by stage over the four pairs, so that no instruction reads the result of the one
+            // just before it (a dependent packed pair back to back costs a wait state)
+            v2f xk[4], xm[4], se[4], so[4], st[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v2f e = pk_add_conj(v[j], prt[j]), o = pk_sub_conj(v[j], prt[j]);
-                v2f tt = pk_cmul(o, tws[j]);
-                xk[j] = e + tt;
-                xm[j] = e - tt;                                  // X[512-k] = conj(xm)
+                se[j] = pk_add_conj(v[j], prt[j]);
+                so[j] = pk_sub_conj(v[j], prt[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                st[j] = pk_cmul_lo(so[j], tws[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                st[j] = pk_cmul_hi(so[j], tws[j], st[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xk[j] = se[j] + st[j];
+                xm[j] = se[j] - st[j];                           // X[512-k] = conj(xm)
             }
             if (OUT == kComplex) {
                 if (valid) {
@@ -784,10 +828,25 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 return;
             }
             float mk[4], mm[4];
+            {
+                // squares of all eight bins, then the sums, then the roots / logs (same reason)
+                v2f qk[4], qm[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
-                mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+                for (int j = 0; j < 4; ++j) {
+                    qk[j] = xk[j] * xk[j];
+                    qm[j] = xm[j] * xm[j];
+                }
+                float pk[4], pm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pk[j] = qk[j].x + qk[j].y;
+                    pm[j] = qm[j].x + qm[j].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mk[j] = bin_from_power<OUT>(pk[j], log_floor);
+                    mm[j] = bin_from_power<OUT>(pm[j], log_floor);
+                }
             }
             const float m256 = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
             if (MEL) {
