@@ -1530,6 +1530,12 @@ int aa_stream_create(const aa_stft_config *cfg, int32_t ring_len, aa_stream **ou
     if (!cfg || !out_stream)
         return fail(AA_ERR_ARG, "aa_stream_create: NULL argument");
     *out_stream = nullptr;
+    // The frame loop advances by hop and needs n_fft samples (stft.rs:273, 436-437): hop == 0 would
+    // emit one frame for ever, hop > n_fft would drive `available` negative (a usize underflow in
+    // the reference).  Both reference instances use hop = n_fft / 4.
+    if (cfg->n_fft <= 0 || cfg->hop <= 0 || cfg->hop > cfg->n_fft)
+        return fail(AA_ERR_ARG, "aa_stream_create: need 0 < hop (%d) <= n_fft (%d)", cfg->hop,
+                    cfg->n_fft);
     if (ring_len == 0)
         ring_len = cfg->n_fft * 4 > 8192 ? cfg->n_fft * 4 : 8192;   // stft.rs:171
     if (ring_len < cfg->n_fft)

@@ -16,6 +16,16 @@ import numpy as np
 from . import _lib
 
 
+def _current_device_index():
+    """The HIP device a plan created now binds to (aa_stft_plan_create uses the current one)."""
+    try:
+        import torch
+
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+    except ImportError:
+        return 0
+
+
 class Stft:
     def __init__(self, n_fft, hop=None, window="hann", output="mag", sample_rate=48000,
                  n_mels=128, n_mfcc=40, fmin=0.0, fmax=0.0, log_floor=0.0):
@@ -39,6 +49,7 @@ class Stft:
         self.n_fft, self.hop, self.output = int(n_fft), int(hop), output
         self.cols = int(self._lib.aa_stft_out_cols(self._plan))
         self.kernel = self._lib.aa_stft_kernel_name(self._plan).decode()
+        self.device_index = _current_device_index()
 
     def close(self):
         if getattr(self, "_plan", None):
@@ -62,7 +73,10 @@ class Stft:
 
     def __call__(self, samples, frame_begin=0, frame_end=None, out=None, stream=None):
         if isinstance(samples, np.ndarray):
-            return self.execute_host(samples)
+            if frame_begin != 0 or frame_end is not None or stream is not None:
+                raise _lib.AaError(_lib.AA_ERR_ARG, "the host path transforms the whole buffer: "
+                                   "frame_begin / frame_end / stream apply to CUDA tensors only")
+            return self.execute_host(samples, out)
         return self.execute_device(samples, frame_begin, frame_end, out, stream)
 
     def execute_host(self, samples, out=None):
@@ -90,9 +104,21 @@ class Stft:
         total = self.num_frames(samples.shape[0])
         if frame_end is None:
             frame_end = total
+        if not 0 <= frame_begin <= frame_end <= total:
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"frame range [{frame_begin}, {frame_end}) is outside "
+                               f"[0, {total}]")
+        if samples.device.index != self.device_index:
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"samples live on cuda:{samples.device.index} but the "
+                               f"plan was created on cuda:{self.device_index}")
         nf = frame_end - frame_begin
         if out is None:
             out = torch.empty((max(nf, 0), self.cols), dtype=torch.float32, device=samples.device)
+        elif not (out.is_cuda and out.device == samples.device and out.dtype == torch.float32
+                  and out.is_contiguous() and out.numel() >= nf * self.cols):
+            # the kernels write nf*cols floats with 16-byte stores: a short or strided `out`
+            # would be a silent out-of-bounds device write
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"out must be a contiguous CUDA float32 tensor on "
+                               f"{samples.device} with at least {nf * self.cols} elements")
         st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
         if nf > 0:
             _lib.check(self._lib.aa_stft_execute_device(self._plan, samples.data_ptr(),
