@@ -153,6 +153,18 @@ SIGNATURES = {
     "aa_shard_frames": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]),
     "aa_shard_samples": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.c_int32, _i64p, _i64p]),
+    "aa_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _vpp]),
+    "aa_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "aa_comm_world": (ctypes.c_int32, [ctypes.c_void_p]),
+    "aa_comm_rank": (ctypes.c_int32, [ctypes.c_void_p]),
+    "aa_comm_backend": (ctypes.c_char_p, []),
+    "aa_comm_barrier": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_scatter_samples": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_void_p]),
+    "aa_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "aa_stream_create": (ctypes.c_int, [ctypes.POINTER(StftConfig), ctypes.c_int32, _vpp]),
     "aa_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_stream_push": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int32, _f32p, _i64p,

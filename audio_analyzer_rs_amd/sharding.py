@@ -70,40 +70,175 @@ def scatter_samples(full, shard, device=None, src=0):
         local.copy_(full[shard.s0:shard.s1])
         return local
     if shard.rank == src:
-        reqs = []
+        ops = []
         for r in range(shard.world):
             f0, f1 = shard_frames(shard.total_frames, shard.world, r)
             s0, s1 = shard_samples(f0, f1, shard.n_fft, shard.hop)
             if r == src:
                 local.copy_(full[s0:s1])
             elif s1 > s0:
-                reqs.append(dist.isend(full[s0:s1].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                ops.append(("send", full[s0:s1], r))
+        _p2p(ops)
     elif shard.local_samples > 0:
-        dist.recv(local, src=src)
+        _p2p([("recv", local, src)])
     return local
 
 
-def gather_rows(rows, shard, dst=None):
-    """rows: this rank's [local_frames, cols] tensor.  dst=None -> all ranks get [F, cols]
-    (all_gather on padded blocks); dst=r -> only rank r does (others return None)."""
+def _p2p(ops):
+    """Run a list of (kind, tensor, peer) point-to-point transfers as ONE grouped batch
+    (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the GPU box)."""
+    import torch.distributed as dist
+
+    if not ops:
+        return
+    batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops]
+    for req in dist.batch_isend_irecv(batch):
+        req.wait()
+
+
+def gather_rows(rows, shard, dst=None, out=None):
+    """rows: this rank's [local_frames, cols] tensor.
+    dst=r    -> rank r returns [F, cols] (written into `out` if given), the others None.  Every
+                rank sends its own UNPADDED block straight into its slice of the destination
+                (grouped point-to-point: what lands on the root is exactly F*cols*4 bytes).
+    dst=None -> all ranks get [F, cols] (all_gather on blocks padded to the largest shard)."""
     import torch
     import torch.distributed as dist
 
     if shard.world == 1:
+        if out is not None:
+            out.copy_(rows)
+            return out
         return rows
     cols = rows.shape[1]
     ranges = shard.all_frame_ranges()
+    if dst is not None:
+        if shard.rank == dst:
+            if out is None:
+                out = torch.empty((shard.total_frames, cols), dtype=rows.dtype, device=rows.device)
+            f0, f1 = ranges[dst]
+            out[f0:f1].copy_(rows)
+            _p2p([("recv", out[g0:g1], r) for r, (g0, g1) in enumerate(ranges) if r != dst and g1 > g0])
+            return out
+        if rows.shape[0] > 0:
+            _p2p([("send", rows.contiguous(), dst)])
+        return None
     cap = max(f1 - f0 for f0, f1 in ranges)
     pad = torch.zeros((cap, cols), dtype=rows.dtype, device=rows.device)
     pad[:rows.shape[0]] = rows
-    if dst is None:
-        blocks = [torch.empty_like(pad) for _ in range(shard.world)]
-        dist.all_gather(blocks, pad)
-    else:
-        blocks = [torch.empty_like(pad) for _ in range(shard.world)] if shard.rank == dst else None
-        dist.gather(pad, blocks, dst=dst)
-        if shard.rank != dst:
-            return None
+    blocks = [torch.empty_like(pad) for _ in range(shard.world)]
+    dist.all_gather(blocks, pad)
     return torch.cat([b[:f1 - f0] for b, (f0, f1) in zip(blocks, ranges)], dim=0)
+
+
+def gather_samples(local, shard, dst=0):
+    """Inverse of scatter_samples: rank `dst` assembles the whole buffer from every rank's
+    [s0, s1) range (the n_fft-hop halos overlap; each rank contributes only its new samples)."""
+    import torch
+
+    ranges = []
+    for r in range(shard.world):
+        f0, f1 = shard_frames(shard.total_frames, shard.world, r)
+        ranges.append(shard_samples(f0, f1, shard.n_fft, shard.hop))
+    if shard.world == 1:
+        return local
+    if shard.rank == dst:
+        full = torch.zeros(shard.n_samples, dtype=local.dtype, device=local.device)
+        s0, s1 = ranges[dst]
+        full[s0:s1].copy_(local)
+        _p2p([("recv", full[a:b], r) for r, (a, b) in enumerate(ranges) if r != dst and b > a])
+        return full
+    if local.numel() > 0:
+        _p2p([("send", local.contiguous(), dst)])
+    return None
+
+
+class Comm:
+    """The C-ABI collectives (`aa_comm_*`, include/aa_stft.h) — what a Rust / C++ host calls; RCCL
+    over xGMI, bound by libaa_stft.so itself (no torch.distributed involved).
+
+        uid = Comm.unique_id() on rank 0, handed to the other ranks (128 bytes, any channel)
+        comm = Comm(uid, world, rank)             # after torch.cuda.set_device(local_rank)
+        mine = comm.scatter_samples(full, n_samples, n_fft, hop, root=0)
+        rows = comm.gather_rows(my_rows, total_frames, root=0)
+    """
+
+    def __init__(self, uid, world, rank):
+        self._lib = _lib.load()
+        if len(uid) != 128:
+            raise _lib.AaError(_lib.AA_ERR_ARG, "a communicator id is 128 bytes")
+        self._uid = ctypes.create_string_buffer(bytes(uid), 128)
+        self._comm = ctypes.c_void_p()
+        _lib.check(self._lib.aa_comm_create(self._uid, int(world), int(rank), ctypes.byref(self._comm)))
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(lib.aa_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def backend():
+        return _lib.load().aa_comm_backend().decode()
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.aa_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream(t, stream):
+        import torch
+
+        return stream if stream is not None else torch.cuda.current_stream(t.device).cuda_stream
+
+    def barrier(self, stream=None):
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(self._lib.aa_comm_barrier(self._comm, st))
+
+    def scatter_samples(self, full, n_samples, n_fft, hop, root=0, stream=None):
+        """full: CUDA float32 [n_samples] on rank `root` (None elsewhere).  Returns this rank's range."""
+        import torch
+
+        shard = ShardPlan(n_samples, n_fft, hop, self.world, self.rank)
+        local = torch.empty(shard.local_samples, dtype=torch.float32, device="cuda")
+        if self.rank == root and not (full.is_cuda and full.dtype == torch.float32 and full.is_contiguous()
+                                      and full.numel() == n_samples):
+            raise _lib.AaError(_lib.AA_ERR_ARG, "full must be a contiguous CUDA float32 tensor of n_samples")
+        _lib.check(self._lib.aa_scatter_samples(
+            self._comm, full.data_ptr() if self.rank == root else None, int(n_samples), int(n_fft), int(hop),
+            int(root), local.data_ptr() if local.numel() else None, local.numel(), self._stream(local, stream)))
+        return local
+
+    def gather_rows(self, rows, total_frames, root=0, out=None, stream=None):
+        """rows: this rank's CUDA float32 [local_frames, cols].  Rank `root` (every rank for
+        root=-1) returns the dense [total_frames, cols] slab, the others None."""
+        import torch
+
+        if not (rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous()):
+            raise _lib.AaError(_lib.AA_ERR_ARG, "rows must be a contiguous 2-D CUDA float32 tensor")
+        f0, f1 = shard_frames(total_frames, self.world, self.rank)
+        if rows.shape[0] != f1 - f0:
+            raise _lib.AaError(_lib.AA_ERR_LEN, f"rank {self.rank} owns {f1 - f0} frames, rows has {rows.shape[0]}")
+        cols = rows.shape[1]
+        receiver = root < 0 or root == self.rank
+        if receiver:
+            if out is None:
+                out = torch.empty((total_frames, cols), dtype=torch.float32, device=rows.device)
+            elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                      and out.numel() >= total_frames * cols):
+                raise _lib.AaError(_lib.AA_ERR_ARG, "out must be a contiguous CUDA float32 [total_frames, cols]")
+        _lib.check(self._lib.aa_gather_rows(self._comm, rows.data_ptr() if rows.numel() else None,
+                                            int(total_frames), int(cols), int(root),
+                                            out.data_ptr() if receiver else None, self._stream(rows, stream)))
+        return out if receiver else None

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 1
+#define AA_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -47,7 +47,7 @@ enum {
     AA_ERR_HIP = -3,         /* HIP runtime error or no device                      */
     AA_ERR_NOMEM = -4,
     AA_ERR_UNSUPPORTED = -5, /* valid request this build does not implement         */
-    AA_ERR_NCCL = -6         /* reserved for collective helpers                     */
+    AA_ERR_NCCL = -6         /* RCCL error, or librccl could not be bound (aa_comm_*) */
 };
 
 /* Last error text of the calling thread ("" if none). Never NULL. */
@@ -357,6 +357,51 @@ int aa_shard_frames(int64_t total_frames, int32_t world, int32_t rank, int64_t *
                     int64_t *f1);
 int aa_shard_samples(int64_t f0, int64_t f1, int32_t n_fft, int32_t hop, int64_t *s0,
                      int64_t *s1);
+
+/* ---- collectives of the sharded job (RCCL over xGMI, one process per GPU) -- */
+/* The partition above needs no collective: every rank transforms its own frame range and keeps
+ * its rows.  These helpers cover the two exchanges a host may still want: the
+ * samples start on ONE GPU (scatter), or one GPU wants every row (gather).  They run on librccl
+ * directly (grouped ncclSend / ncclRecv, unpadded blocks, asynchronous on `stream`), so a Rust or
+ * C++ host needs nothing but this library.  librccl is bound at run time; without it every entry
+ * point returns AA_ERR_NCCL.  The reference has no counterpart (it is a single-process CPU
+ * engine); the seam these sit behind is the frame loop of stft.rs:273-318 run over a shard.
+ *
+ * Bootstrap as with NCCL: rank 0 calls aa_comm_unique_id and hands the 128 bytes to the other
+ * ranks by any means it has (a file, a pipe, MPI, the launcher's store); then EVERY rank calls
+ * aa_comm_create with the same id, its rank and the world size, after selecting its GPU
+ * (hipSetDevice) — the communicator binds to the current device. */
+#define AA_COMM_ID_BYTES 128
+typedef struct aa_comm_id {
+    char bytes[AA_COMM_ID_BYTES];
+} aa_comm_id;
+typedef struct aa_comm aa_comm;
+
+int aa_comm_unique_id(aa_comm_id *out_id);
+int aa_comm_create(const aa_comm_id *id, int32_t world, int32_t rank, aa_comm **out_comm);
+int aa_comm_destroy(aa_comm *comm);
+int32_t aa_comm_world(const aa_comm *comm);
+int32_t aa_comm_rank(const aa_comm *comm);
+/* Which librccl was bound ("librccl.so.1 already mapped in this process", a path, ...), or the
+ * reason none could be.  Never NULL. */
+const char *aa_comm_backend(void);
+/* Every rank exchanges one float with every rank (itself included) and waits for the stream:
+ * returns when all ranks have entered. */
+int aa_comm_barrier(aa_comm *comm, void *stream);
+
+/* Rank `root` holds the whole buffer full_dev[0, n_samples) (ignored elsewhere); every rank
+ * receives the range aa_shard_samples gives it — its frames plus the n_fft-hop halo — into
+ * local_dev (capacity in floats; AA_ERR_LEN if too small).  Point-to-point, not a broadcast: the
+ * root sends n_samples + (world-1)*(n_fft-hop) floats in all. */
+int aa_scatter_samples(aa_comm *comm, const float *full_dev, int64_t n_samples, int32_t n_fft,
+                       int32_t hop, int32_t root, float *local_dev, int64_t local_capacity,
+                       void *stream);
+/* Every rank contributes its rows_dev[f1-f0][cols] (the frame range aa_shard_frames gives it);
+ * rank `root` receives the dense [total_frames][cols] slab in out_dev (ignored elsewhere), each
+ * block landing at its global row.  root == -1: every rank receives the slab (all-gather).
+ * rows_dev may already be the rank's own slice of out_dev (no copy then). */
+int aa_gather_rows(aa_comm *comm, const float *rows_dev, int64_t total_frames, int32_t cols,
+                   int32_t root, float *out_dev, void *stream);
 
 /* ---- streaming front end (ring-buffer ingest of stft.rs:198-201, 240-266) -- */
 typedef struct aa_stream aa_stream;

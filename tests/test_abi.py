@@ -63,7 +63,7 @@ def test_header_is_plain_c_and_structs_match_the_ctypes_mirrors(tmp_path):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.aa_abi_version() == 1
+    assert lib.aa_abi_version() == 2
     assert isinstance(lib.aa_last_error(), bytes)
 
 
@@ -151,3 +151,21 @@ def test_synthetic_corpus_is_shard_consistent():
         seq.append(s)
     assert np.array_equal(signals.lcg_states(12345, 0, 5), np.array(seq, dtype=np.uint64))
     assert np.array_equal(signals.lcg_states(12345, 2, 3), np.array(seq[2:], dtype=np.uint64))
+
+
+def test_comm_argument_errors_without_a_gpu(lib):
+    """aa_comm_*: argument checks come before anything touches RCCL or a device."""
+    from audio_analyzer_rs_amd import _lib
+
+    comm = ctypes.c_void_p()
+    uid = ctypes.create_string_buffer(128)
+    assert lib.aa_comm_create(None, 2, 0, ctypes.byref(comm)) == _lib.AA_ERR_ARG
+    assert lib.aa_comm_create(uid, 0, 0, ctypes.byref(comm)) == _lib.AA_ERR_ARG
+    assert lib.aa_comm_create(uid, 2, 2, ctypes.byref(comm)) == _lib.AA_ERR_ARG
+    assert lib.aa_comm_unique_id(None) == _lib.AA_ERR_ARG
+    assert lib.aa_comm_destroy(None) == _lib.AA_OK
+    assert lib.aa_comm_world(None) == 0 and lib.aa_comm_rank(None) == -1
+    assert lib.aa_comm_barrier(None, None) == _lib.AA_ERR_ARG
+    assert lib.aa_gather_rows(None, None, 10, 513, 0, None, None) == _lib.AA_ERR_ARG
+    assert lib.aa_scatter_samples(None, None, 10, 1024, 256, 0, None, 0, None) == _lib.AA_ERR_ARG
+    assert isinstance(lib.aa_comm_backend(), bytes)

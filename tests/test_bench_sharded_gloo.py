@@ -1,0 +1,92 @@
+"""The N > 1 branch of bench.py (BASELINE configs[3]: one corpus, frame-range sharded, strong
+scaling; compute-only and scatter + compute + gather legs) executed by CI with world size 2 over
+gloo.  `bench.run_sharded` is the very function the 8-GPU run calls; only the per-rank compute is
+swapped for the CPU oracle (the HIP path needs a GPU) and the corpus is 3 s instead of 1 h."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleCompute:
+    """CPU stand-in with the interface of bench.HipCompute."""
+
+    cols, kernel, stream = 513, "cpu-oracle-standin", None
+
+    def to_device(self, x_np):
+        return torch.from_numpy(x_np)
+
+    def empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32)
+
+    def execute(self, x, nf, out):
+        import oracle
+
+        if nf > 0:
+            out.copy_(torch.from_numpy(oracle.stft(x.numpy(), 1024, 256, kind="mag")))
+
+    def sync(self):
+        pass
+
+    def events(self):
+        return None
+
+
+def _worker(rank, world, port, total, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        res = bench.run_sharded(dist, OracleCompute(), world, rank, total, steps=2, warmup=1, e2e_passes=2,
+                                ramp_s=0.0)
+        if rank == 0:
+            json.dump(res, open(os.path.join(tmpdir, "result.json"), "w"))
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharded_path_over_gloo(tmp_path, world):
+    total = 3 * 48000
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    res = json.load(open(tmp_path / "result.json"))
+    frames = (total - 1024) // 256 + 1
+    assert res["n_gpus"] == world and res["n_ranks_seen"] == world
+    assert res["scaling"] == "strong" and res["steps"] == 2 and res["warmup"] == 1
+    assert res["config"]["frames_total"] == frames
+    assert res["value"] > 0 and res["ms_per_step"] > 0
+    assert abs(res["value"] - frames * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"]
+    # the rows rank 0 gathered from every rank agree with the float64 truth
+    assert res["post_check_max_err"] <= res["post_check_tol"]
+    for k in ("scatter_ms", "compute_ms", "gather_ms", "total_ms", "frames_per_s"):
+        assert res["e2e"][k] > 0
+    assert res["roofline"]["frames_per_launch"] == frames // world
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit):
+        bench.main()

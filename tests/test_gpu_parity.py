@@ -795,3 +795,29 @@ def test_full_size_sharded_equals_whole(aa, torch_mod, corpus_10min):
             assert plan.num_frames(local.shape[0]) == sp.local_frames
             parts.append(plan(local))
         assert torch_mod.equal(torch_mod.cat(parts), whole)
+
+
+# --------------------------------------------- BASELINE configs[0]: the PCM16 stand-in --
+def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
+    """BASELINE configs[0]: 1024-pt STFT, hop 256, Hann over `test_output.wav`.  The file is stripped
+    from the reference (.MISSING_LARGE_BLOBS), so the stand-in is 60 s of the synthetic corpus written
+    exactly as the recorder writes it (16-bit PCM mono 48 kHz, (clamp(s,-1,1)*32767) as i16,
+    src/audio_io/recorder.rs:81-85), read back and decoded i16/32768.  The HIP path on the decoded
+    samples against the CPU restatement (<= 1e-5) and the float64 truth (<= 5e-6), every row."""
+    from conftest import TOL_VS_ORACLE, TOL_VS_TRUTH
+
+    x = aa.signals.synth_corpus(0, 60 * 48000)
+    path = tmp_path / "test_output.wav"
+    aa.wav.write_wav(path, x, 48000)
+    pcm, sr = aa.wav.read_wav(path)
+    assert sr == 48000 and pcm.dtype == np.float32 and pcm.shape == x.shape
+    assert np.array_equal(pcm, aa.signals.pcm16_roundtrip(x))
+    assert np.max(np.abs(pcm - x)) <= 1.0 / 32767.0 + 1e-7          # quantisation only
+    plan = aa.Stft(1024, 256, output="mag")
+    assert plan.kernel == "wave1024"
+    got = plan(torch_mod.from_numpy(pcm).cuda()).cpu().numpy()
+    ref = oracle_mod.stft(pcm, 1024, 256, kind="mag")
+    assert got.shape == ref.shape == (11247, 513)
+    assert nerr(got, ref.astype(np.float64)).max() <= TOL_VS_ORACLE
+    truth = oracle_mod.truth.stft_mag(pcm, 1024, 256, oracle_mod.hann_window(1024))
+    assert nerr(got, truth).max() <= TOL_VS_TRUTH
