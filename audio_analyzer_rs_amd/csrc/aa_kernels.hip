@@ -59,6 +59,17 @@ __device__ __forceinline__ void lds_wait_8(v2f &a, v2f &b, v2f &c, v2f &d, v2f &
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
 }
+// "At most N vector-memory operations still in flight."  vmcnt retires in issue order and counts
+// stores, so with N = the number of row stores a wave issues per chunk AFTER the LDS-DMA loads of
+// the next chunk, the loads are complete while those stores stay in flight.  N must never exceed
+// that number (a larger N would let the last DMA piece still be flying): every kernel derives it
+// from the constexpr store count of the epilogue it instantiates.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
@@ -186,6 +197,30 @@ __device__ __forceinline__ void pk_dft8(v2f (&v)[8])
     v2f c1 = a1 + a3, u = a1 - a3;                   // c3 = -i u
     v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);   // b0 +- (-i b2)
     const v2f e = p - q, g = p + q;                  // d1 = h e, w = h g
+    v[0] = c0 + c1; v[4] = c0 - c1;
+    v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
+    v[1] = d0 + e * hp; v[5] = d0 - e * hp;
+    v[3] = pk_fma_mi(g, hp, d2); v[7] = pk_fma_pi(g, hp, d2);
+}
+
+// pk_dft8 of (v[j] * w[j]): the window multiply of stft.rs:296-299 folded into the first butterfly
+// stage - a_i = v_i w_i + v_{i+4} w_{i+4} is one multiply and one FMA, b_i one more FMA - 12 packed
+// instructions where the separate multiply + add / sub take 16.  (The products of the upper four
+// registers are not rounded on their own: the result is closer to the exact one by < 1 ulp.)
+__device__ __forceinline__ void pk_dft8_windowed(v2f (&v)[8], const v2f (&w)[8])
+{
+    const v2f hp = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f t0 = v[0] * w[0], t1 = v[1] * w[1], t2 = v[2] * w[2], t3 = v[3] * w[3];
+    const v2f a0 = __builtin_elementwise_fma(v[4], w[4], t0), b0 = __builtin_elementwise_fma(-v[4], w[4], t0);
+    const v2f a1 = __builtin_elementwise_fma(v[5], w[5], t1), b1 = __builtin_elementwise_fma(-v[5], w[5], t1);
+    const v2f a2 = __builtin_elementwise_fma(v[6], w[6], t2), b2 = __builtin_elementwise_fma(-v[6], w[6], t2);
+    const v2f a3 = __builtin_elementwise_fma(v[7], w[7], t3), b3 = __builtin_elementwise_fma(-v[7], w[7], t3);
+    const v2f p = pk_add_mi(b1, b1);
+    const v2f q = pk_add_pi(b3, b3);
+    v2f c0 = a0 + a2, c2 = a0 - a2;
+    v2f c1 = a1 + a3, u = a1 - a3;
+    v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);
+    const v2f e = p - q, g = p + q;
     v[0] = c0 + c1; v[4] = c0 - c1;
     v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
     v[1] = d0 + e * hp; v[5] = d0 - e * hp;
@@ -584,6 +619,16 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 // the interleaved phases apart); a static youngest-first order, a progress-based priority and a
 // dynamic chunk queue were measured too (tools/experiments/) and lost.
 // step is uniform across the workgroup; only the issue order changes, never a result.
+// Experiment switches of stft_wave1024_kernel (tools/ab_sustained.py builds one library per setting).
+#ifndef AA_V_WINFMA
+#define AA_V_WINFMA 0      // window multiply folded into the first butterfly stage of pass A
+#endif
+#ifndef AA_V_PAIR
+#define AA_V_PAIR 0        // a wave takes two ADJACENT frames of the chunk; their rows leave as one 4104-byte piece
+#endif
+#ifndef AA_V_TAIL
+#define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
+#endif
 #ifndef AA_PRIO_ROTATE
 #define AA_PRIO_ROTATE 1      // 0: diagnostic builds without the rotation (tools/ab_sustained.py)
 #endif
@@ -642,6 +687,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    constexpr bool PAIR = AA_V_PAIR && WIDE && !MEL && OUT != kComplex;
+    // global stores a wave issues for its two rows of a full 8-frame chunk (every one is issued by
+    // every wave: the lane masks never empty the wave) - the count the chunk-top wait leaves in flight
+    constexpr int kRowStoresPerChunk = OUT == kComplex ? (WIDE ? 2 * 5 : 2 * 9)     // 4 dwordx4 + 1 dwordx2 | 9 dwordx2
+                                       : !WIDE         ? 2 * 9                      // 9 dwords per row
+                                       : PAIR          ? 5                          // 4 dwordx4 + 1 dwordx2 per row PAIR
+                                                       : 2 * 3;                     // 2 dwordx4 + 1 dword per row
     const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
@@ -690,6 +742,10 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     for (int j = 0; j < 4; ++j)
         tws[j] = v2f{tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]};
 
+    // a lane of the head / tail store is active iff tail_lo <= sh <= tail_lo + tail_span
+    // (lanes 0-3: sh <= lane; lanes 4-7: sh >= lane - 4; the others never)
+    const int tail_lo = lane < 4 ? 0 : lane < 8 ? lane - 4 : 4;
+    const unsigned tail_span = lane < 4 ? (unsigned)lane : lane < 8 ? (unsigned)(7 - lane) : 0u;
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
@@ -701,13 +757,13 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
         // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
         if ((ABL & 64) || c == c0 || frames_per_wg != 8)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vmcnt_le<0>();
         else if (MEL && sch.n_mels > 64)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // 2 dword stores per mel row
+            wait_vmcnt_le<4>();                                  // 2 dword stores per mel row, 2 rows
         else if (MEL)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            wait_vmcnt_le<2>();
         else
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // 3 row stores per frame
+            wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         const int prio_step = (int)(blockIdx.x >> 8) + 4 * (c - c0);   // dispatch round + quarter chunks
@@ -729,10 +785,14 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
             v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
         };
         auto pass_a = [&](v2f (&v)[8]) {
+            if (AA_V_WINFMA) {
+                pk_dft8_windowed(v, win);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = v[j] * win[j];
-            pk_dft8(v);
+                for (int j = 0; j < 8; ++j)
+                    v[j] = v[j] * win[j];
+                pk_dft8(v);
+            }
             pk_twiddle7(v, twA);
         };
         auto exchange1 = [&](v2f (&v)[8]) {           // E1 through LDS
@@ -815,7 +875,35 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                 xm[j] = se[j] - st[j];                           // X[512-k] = conj(xm)
             }
             if (OUT == kComplex) {
-                if (valid) {
+                if (WIDE) {
+                    // Row (4104 bytes, 8-byte aligned: the shift is one complex for odd rows) through
+                    // the scratch, so that it leaves as 4 aligned nontemporal dwordx4 stores + one
+                    // dwordx2 (complex 0 of an odd row, complex 512 of an even one) instead of 9
+                    // scattered 8-byte stores: scr[0] <-> the 16-byte-aligned address at or below the row.
+                    const int shc = (row0 + t) & 1;
+                    v2f *lrow = scr + shc;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        lrow[lane + 64 * j] = xk[j];
+                        lrow[512 - lane - 64 * j] = v2f{xm[j].x, -xm[j].y};
+                    }
+                    if (lane == 0)
+                        lrow[256] = v2f{2.0f * v[4].x, -2.0f * v[4].y};
+                    __builtin_amdgcn_wave_barrier();
+                    const v4f *lw4 = reinterpret_cast<const v4f *>(scr) + shc + lane;
+                    const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
+                    const v2f edge = scr[shc ? 1 : 512];
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid) {
+                        v4f *gw4 = reinterpret_cast<v4f *>(row - 2 * shc) + shc + lane;
+                        __builtin_nontemporal_store(q0, gw4);
+                        __builtin_nontemporal_store(q1, gw4 + 64);
+                        __builtin_nontemporal_store(q2, gw4 + 128);
+                        __builtin_nontemporal_store(q3, gw4 + 192);
+                        if (lane == 0)
+                            reinterpret_cast<v2f *>(row)[shc ? 0 : 512] = edge;
+                    }
+                } else if (valid) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int kk = lane + 64 * j;
@@ -865,6 +953,52 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     asm volatile("" ::"v"(mk[j]), "v"(mm[j]));
+            } else if (PAIR && frames_per_wg == 8) {
+                // The wave's two frames are ADJACENT (t = 2 wave, 2 wave + 1): their rows are one
+                // 4104-byte piece whose start is 0 or 2 floats past a 16-byte boundary (513 = 1 mod 4,
+                // the chunk's first row is a multiple of 8).  Both rows are staged (slot 0, slot 1),
+                // then the piece leaves as 4 full nontemporal dwordx4 stores + one dwordx2 (floats
+                // 1024-1025 of the window when sh2 == 0, floats 2-3 when sh2 == 2).
+                const int sh2 = (row0 + t - slot) & 3;                   // 0 or 2
+                float *lrow = reinterpret_cast<float *>(scr) + sh2 + slot * NB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lrow[lane + 64 * j] = mk[j];
+                    lrow[512 - lane - 64 * j] = mm[j];
+                }
+                if (lane == 0)
+                    lrow[256] = m256;
+                if (slot == 1) {
+                    __builtin_amdgcn_wave_barrier();
+                    const float *lw = reinterpret_cast<const float *>(scr);
+                    float *gw = row - NB - sh2;                          // window of row a
+                    if (valid) {
+                        const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
+                        const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
+                        const int eo = sh2 ? 2 : 1024;
+                        const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
+                        __builtin_amdgcn_wave_barrier();
+                        v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
+                        __builtin_nontemporal_store(q0, gw4);
+                        __builtin_nontemporal_store(q1, gw4 + 64);
+                        __builtin_nontemporal_store(q2, gw4 + 128);
+                        __builtin_nontemporal_store(q3, gw4 + 192);
+                        if (lane == 0)
+                            *reinterpret_cast<v2f *>(gw + eo) = edge;
+                    } else {
+                        // ragged last chunk: only row a exists - the single-row scheme below
+                        v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                        v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
+                        const int hi = lane < 4 ? lane : 508 + lane;
+                        const float hv = lw[lane < 8 ? hi : 0];
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                        if (lane < 63)
+                            __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                        if ((unsigned)(sh2 - tail_lo) <= tail_span)
+                            gw[hi] = hv;
+                    }
+                }
             } else if (WIDE) {
                 // Row through LDS so it leaves as 16-byte-aligned nontemporal dwordx4 stores.
                 // The row starts at float 513 r of a 16-byte-aligned buffer, so its aligned
@@ -892,7 +1026,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                     if (lane < 63)
                         __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
                     // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
-                    const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
+                    const bool ok = AA_V_TAIL ? (unsigned)(sh - tail_lo) <= tail_span
+                                              : lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
                     if (ok)
                         gw[hi] = hv;
                 }
@@ -912,7 +1047,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
             // independent work of one frame fills the LDS round trips and VALU dependency stalls
             // of the other.  The single scratch area is safe: DS operations of a wave execute in
             // program order, and each exchange's reads are issued before the next one's writes.
-            const int ta = wave, tb = wave + 4;
+            const int ta = PAIR ? 2 * wave : wave, tb = PAIR ? 2 * wave + 1 : wave + 4;
             if (ta < nf) {
                 const bool vb = tb < nf;   // ragged last chunk: B computes on stale LDS, stores nothing
                 v2f va[8], vbv[8], pa[4], pb[4];
@@ -1032,6 +1167,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    // global stores a wave issues for its ONE row of a full 4-frame chunk (see stft_wave1024_kernel)
+    constexpr int kRowStoresPerChunk = OUT == kComplex ? (WIDE ? 9 : 17)      // 8 dwordx4 + 1 dwordx2 | 17 dwordx2
+                                       : WIDE          ? 5                    // 4 dwordx4 + head / tail dword
+                                                       : 17;                  // 17 dwords
     const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
     float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;
@@ -1083,14 +1222,14 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
         const int cur = (c - c0) & 1;
         // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
         // row in the previous (full) chunk, after issuing this chunk's DMA loads
-        if (c == c0 || frames_per_wg != 4 || OUT == kComplex || (!MEL && !WIDE))
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c == c0 || frames_per_wg != 4)
+            wait_vmcnt_le<0>();
         else if (MEL && sch.n_mels > 64)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            wait_vmcnt_le<2>();
         else if (MEL)
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            wait_vmcnt_le<1>();
         else
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // 4 dwordx4 pieces + head/tail dwords
+            wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority
@@ -1150,7 +1289,52 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                 xm[j] = ee - tt;                       // X[1024-k] = conj(xm)
             }
             const v2f z512 = zh[0];                    // lane 0: Z[512]; X[512] = 2 conj(Z[512])
-            if (OUT == kComplex) {
+            if (OUT == kComplex && WIDE) {
+                // Row (8200 bytes, 8-byte aligned: odd rows start one complex past a 16-byte boundary)
+                // through the scratch in two halves, so that it leaves as 8 aligned nontemporal
+                // dwordx4 stores + one dwordx2 (complex 0 of an odd row, complex 1024 of an even one).
+                // scr[0] <-> the aligned address at or below complex 0 (first half) / complex 512.
+                const int shc = (row0 + t) & 1;
+                const v2f x512 = v2f{2.0f * z512.x, -2.0f * z512.y};
+                v2f *lrow = scr + shc;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    lrow[lane + 64 * j] = xk[j];
+                if (lane == 0)
+                    lrow[512] = x512;
+                __builtin_amdgcn_wave_barrier();
+                const v4f *lw4 = reinterpret_cast<const v4f *>(scr) + shc + lane;
+                v4f *gw4 = reinterpret_cast<v4f *>(row - 2 * shc) + shc + lane;
+                {
+                    const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
+                    const v2f x0 = scr[1];                         // complex 0 of an odd row
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_nontemporal_store(q0, gw4);
+                    __builtin_nontemporal_store(q1, gw4 + 64);
+                    __builtin_nontemporal_store(q2, gw4 + 128);
+                    __builtin_nontemporal_store(q3, gw4 + 192);
+                    if (lane == 0 && shc)
+                        reinterpret_cast<v2f *>(row)[0] = x0;
+                }
+                // second half: complex k (512..1024) at scr[k - 512 + shc]
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    lrow[512 - lane - 64 * j] = v2f{xm[j].x, -xm[j].y};
+                if (lane == 0)
+                    lrow[0] = x512;
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
+                    const v2f x1024 = scr[512];                    // complex 1024 of an even row
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_nontemporal_store(q0, gw4 + 256);
+                    __builtin_nontemporal_store(q1, gw4 + 320);
+                    __builtin_nontemporal_store(q2, gw4 + 384);
+                    __builtin_nontemporal_store(q3, gw4 + 448);
+                    if (lane == 0 && !shc)
+                        reinterpret_cast<v2f *>(row)[1024] = x1024;
+                }
+            } else if (OUT == kComplex) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = lane + 64 * j;
@@ -1922,7 +2106,12 @@ static int persistent_grid(K kernel, size_t lds)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave1024Threads, lds) != hipSuccess ||
         per_cu < 1)
         per_cu = 1;
-    return cus * per_cu;
+    // AA_GRID_MULT (experiments): that many dispatch generations per resident slot instead of one
+    // persistent workgroup (the hardware dispatcher then balances the tail)
+    int mult = 1;
+    if (const char *e = getenv("AA_GRID_MULT"))
+        mult = atoi(e) > 0 ? atoi(e) : 1;
+    return cus * per_cu * mult;
 }
 
 template <int K>
@@ -1933,8 +2122,8 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
-    static int cached_grid = 0;
-    static size_t cached_lds = 0;
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
         cached_grid = persistent_grid(stft_wave1024_kernel<K, 0, true>, lds);
         cached_lds = lds;
@@ -1961,7 +2150,7 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
         return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
-    const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
         return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
@@ -1988,8 +2177,8 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     const size_t lds = wave2048_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
-    static int cached_grid = 0;
-    static size_t cached_lds = 0;
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
         cached_grid = persistent_grid(stft_wave2048_kernel<K, true>, lds);
         cached_lds = lds;
@@ -2013,7 +2202,7 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
-    const bool wide = out_kind != kComplex && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
         return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
@@ -2037,8 +2226,8 @@ static hipError_t launch_wave_small_kind(bool wide, const float *x, float *out, 
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     const size_t lds = wave_small_lds_bytes(N, frames_per_wg, hop);
-    static int cached_grid = 0;
-    static size_t cached_lds = 0;
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
         cached_grid = persistent_grid(stft_wave_small_kernel<N, K, true>, lds);
         cached_lds = lds;

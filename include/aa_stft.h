@@ -110,6 +110,21 @@ enum {
     AA_OUT_MFCC = 5      /* DCT-II(ortho) of log-mel, n_mfcc floats      — build-defined     */
 };
 
+/* Range contract of AA_OUT_MAG.  The reference's `c.norm()` is hypot(re, im) (stft.rs:314-318); the
+ * kernels compute sqrt(re*re + im*im) in f32 (one v_sqrt_f32 per bin — hypot's rescaling would cost
+ * the bandwidth-bound kernels ~5 % for inputs the reference's own pipeline cannot produce: its samples
+ * are clamped to |x| <= 0.97, dynamics.rs:319-330, so |X| <= 0.97 * n_fft / 2).  Measured on gfx950
+ * (tools/probe_mag_range.py, tests/test_gpu_parity.py::test_mag_edge_values):
+ *   2^-63 (1.1e-19) <= |X| <= 2^63.9 (1.8e19)  within 2 ulp of hypotf(re, im) of the same f32 bin;
+ *   |X| > 1.845e19 (re*re + im*im overflows)     +inf, where hypot returns the finite value;
+ *   |X| < 2^-63 (the sum of squares is subnormal) 0 (flushed), where hypot returns the tiny value;
+ *                                                 subnormal INPUT samples transform to 0 as well;
+ *   a frame that holds a NaN or an Inf sample     every bin of THAT frame is NaN or Inf — as in the
+ *                                                 reference, where the FFT spreads it to all bins —
+ *                                                 but a bin with (re, im) = (inf, NaN) reads NaN here
+ *                                                 and +inf from hypot; other frames are unaffected.
+ * AA_OUT_COMPLEX (process_forward's own output, fft.rs:33-35) has no such limits: callers that need
+ * hypot semantics outside the range above take the complex rows and apply hypotf themselves. */
 typedef struct aa_stft_config {
     int32_t n_fft;       /* window / transform length: 2048 tuner (stft.rs:170), 256 onset
                             (onset.rs:122); BASELINE bench: 1024                           */

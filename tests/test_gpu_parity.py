@@ -812,7 +812,7 @@ def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
     pcm, sr = aa.wav.read_wav(path)
     assert sr == 48000 and pcm.dtype == np.float32 and pcm.shape == x.shape
     assert np.array_equal(pcm, aa.signals.pcm16_roundtrip(x))
-    assert np.max(np.abs(pcm - x)) <= 1.0 / 32767.0 + 1e-7          # quantisation only
+    assert np.max(np.abs(pcm - x)) <= 2.0 / 32768.0                 # truncation + the 32767 / 32768 gain only
     plan = aa.Stft(1024, 256, output="mag")
     assert plan.kernel == "wave1024"
     got = plan(torch_mod.from_numpy(pcm).cuda()).cpu().numpy()
@@ -821,3 +821,56 @@ def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
     assert nerr(got, ref.astype(np.float64)).max() <= TOL_VS_ORACLE
     truth = oracle_mod.truth.stft_mag(pcm, 1024, 256, oracle_mod.hann_window(1024))
     assert nerr(got, truth).max() <= TOL_VS_TRUTH
+
+
+# ------------------------------------------------ |X| outside the audio range (aa_stft.h) --
+@pytest.mark.parametrize("n", [1024, 2048, 256, 64])
+def test_mag_edge_values(aa, torch_mod, n):
+    """The range contract of AA_OUT_MAG written in include/aa_stft.h: sqrt(re^2 + im^2) against the
+    hypot semantics of the reference's c.norm() (stft.rs:314-318) for inputs scaled by 1e+-18 and
+    beyond, subnormal samples, NaN and +-Inf — through the C ABI, back-to-back frames, no window
+    (what `FftProcessor::process_forward` + `norm()` sees)."""
+    rng = np.random.default_rng(n)
+    base = rng.uniform(-1, 1, n * 8).astype(np.float32)
+    mplan = aa.Stft(n, n, window="rect", output="mag")
+    cplan = aa.Stft(n, n, window="rect", output="complex")
+
+    def run(x):
+        xd = torch_mod.from_numpy(x).cuda()
+        c = cplan(xd).cpu().numpy()
+        return mplan(xd).cpu().numpy(), c, np.hypot(c.real.astype(np.float64), c.imag.astype(np.float64))
+
+    ulp2 = 2.0 * 2.0 ** -23
+    # inside the range, far from audio levels on both sides: hypotf to 2 ulp
+    for k in (-18, -10, 0, 10, 17):
+        got, _, hyp = run((base.astype(np.float64) * 10.0 ** k).astype(np.float32))
+        ok = (hyp >= 2.0 ** -62) & (hyp <= 1.8e19)
+        assert ok.mean() > 0.98
+        assert np.max(np.abs(got[ok] - hyp[ok]) / hyp[ok]) <= ulp2
+    # overflow of the sum of squares: +inf above 1.845e19, exact below
+    got, _, hyp = run((base.astype(np.float64) * 2e18).astype(np.float32))
+    over, under = hyp > 1.86e19, hyp < 1.83e19
+    assert over.any() and under.any()
+    assert np.all(np.isposinf(got[over]))
+    assert np.max(np.abs(got[under] - hyp[under]) / hyp[under]) <= ulp2
+    # underflow: the sum of squares is subnormal below 2^-63 and is flushed
+    got, _, hyp = run((base.astype(np.float64) * 1e-20).astype(np.float32))
+    tiny, norm = hyp < 2.0 ** -64, hyp > 2.0 ** -62
+    assert np.all(got[tiny] == 0.0)
+    if norm.any():
+        assert np.max(np.abs(got[norm] - hyp[norm]) / hyp[norm]) <= 1e-6
+    assert np.all(np.isfinite(got)) and np.all(got <= hyp * (1 + ulp2) + 1e-45)
+    # subnormal samples transform to zeros, never to garbage
+    got, _, _ = run((base.astype(np.float64) * 1e-41).astype(np.float32))
+    assert np.all(got == 0.0)
+    # NaN / Inf stay inside their frame
+    clean, _, _ = run(base)
+    for bad in (np.nan, np.inf, -np.inf):
+        x = base.copy()
+        x[n + 5] = bad                                     # frame 1
+        got, _, _ = run(x)
+        assert not np.isfinite(got[1]).any()
+        if np.isnan(bad):
+            assert np.isnan(got[1]).all()
+        keep = [0, 2, 3, 4, 5, 6, 7]
+        assert np.array_equal(got[keep], clean[keep])
