@@ -624,7 +624,7 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #define AA_V_WINFMA 0      // window multiply folded into the first butterfly stage of pass A
 #endif
 #ifndef AA_V_PAIR
-#define AA_V_PAIR 0        // a wave takes two ADJACENT frames of the chunk; their rows leave as one 4104-byte piece
+#define AA_V_PAIR 1        // a wave takes two ADJACENT frames of the chunk; their rows leave as one 4104-byte piece
 #endif
 #ifndef AA_V_TAIL
 #define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
