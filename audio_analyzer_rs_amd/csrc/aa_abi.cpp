@@ -366,23 +366,88 @@ void build_wave2048_table(const float *window, std::vector<float> *tab)
     }
 }
 
-// Per-lane constants of stft_wave_small_kernel (n_fft 256 / 512), [kWave256Rows][64]; the lane
+// Frame reads of stft_wave_small_kernel without LDS bank conflicts.  A wave reads FPW frames at once
+// (lane = 8 q' + gamma, gamma = (frame slot, c)); with hop a multiple of 64 floats - the reference's
+// onset geometry 256 / 64, onset.rs:122-123 - every frame slot starts in the same bank, and the FPW
+// frames of one ds_read_b64 collide 4-fold.  Two relabelings move a frame slot to other banks at no
+// cost in the kernel: `flip` (the slot's lanes take q' ^ 4: +8 banks) and `rot` (the slot loads block
+// (j + 1) mod 8 into register j: + 2 LPF banks; the radix-8 over j then yields W8^(-k) X[k], which
+// the per-lane pass-A twiddles absorb).  The (flip, rot) of every slot is chosen by simulating the
+// eight reads on the 64 x 4-byte banks, 32 lanes per pass.
+static int small_read_passes(int n_fft, int hop, int stages, int FPW, int LPF, const int *flip, const int *rot)
+{
+    int total = 0;
+    for (int j = 0; j < 8; ++j)
+        for (int half = 0; half < 2; ++half) {
+            int words[64][8], cnt[64];
+            std::memset(cnt, 0, sizeof cnt);
+            for (int lane = 32 * half; lane < 32 * half + 32; ++lane) {
+                const int gam = lane & 7, c = gam & ((1 << stages) - 1), f = gam >> stages;
+                const int crev = stages < 2 ? c : (((c & 1) << 1) | (c >> 1));
+                const int q = ((lane >> 3) ^ (flip[f] ? 4 : 0)) + 8 * crev;
+                const int fl = f * hop + 2 * (LPF * ((j + rot[f]) & 7) + q);    // float index of the b64
+                for (int h = 0; h < 2; ++h) {
+                    const int bank = (fl + h) & 63, word = fl + h;
+                    bool seen = false;
+                    for (int i = 0; i < cnt[bank]; ++i)
+                        seen = seen || words[bank][i] == word;
+                    if (!seen && cnt[bank] < 8)
+                        words[bank][cnt[bank]++] = word;
+                }
+            }
+            int worst = 1;
+            for (int b = 0; b < 64; ++b)
+                worst = cnt[b] > worst ? cnt[b] : worst;
+            total += worst;
+        }
+    (void)n_fft;
+    (void)FPW;
+    return total;
+}
+
+// Per-lane constants of stft_wave_small_kernel (n_fft 128 / 256 / 512), [kWave256Rows][64]; the lane
 // map and row meaning are described above that kernel.
-void build_wave_small_table(int n_fft, const float *window, std::vector<float> *tab)
+void build_wave_small_table(int n_fft, int hop, const float *window, std::vector<float> *tab)
 {
     tab->assign((size_t)aa::kWave256Rows * 64, 0.0f);
     float *T = tab->data();
     const int M = n_fft / 2, LPF = M / 8, FPW = 64 / LPF, stages = LPF == 8 ? 0 : LPF == 16 ? 1 : 2, PPF = M / 2 + 1;
+    // (flip, rot) per frame slot: exhaustive over the 4^FPW assignments (<= 65536), fewest passes,
+    // ties to the plain map
+    int flip[8] = {0}, rot[8] = {0}, best = small_read_passes(n_fft, hop, stages, FPW, LPF, flip, rot);
+    if (best > 16) {
+        int bf[8] = {0}, br[8] = {0};
+        for (int code = 1; code < (1 << (2 * FPW)) && best > 16; ++code) {
+            int f2[8], r2[8];
+            for (int f = 0; f < FPW; ++f) {
+                f2[f] = (code >> (2 * f)) & 1;
+                r2[f] = (code >> (2 * f + 1)) & 1;
+            }
+            const int passes = small_read_passes(n_fft, hop, stages, FPW, LPF, f2, r2);
+            if (passes < best) {
+                best = passes;
+                std::memcpy(bf, f2, sizeof bf);
+                std::memcpy(br, r2, sizeof br);
+            }
+        }
+        std::memcpy(flip, bf, sizeof flip);
+        std::memcpy(rot, br, sizeof rot);
+    }
     for (int lane = 0; lane < 64; ++lane) {
-        // before the exchange: lane = 8 q' + gamma, gamma = (frame, c); q = q' + 8 bitrev(c)
-        const int gam = lane & 7, c = gam & ((1 << stages) - 1), qp = lane >> 3;
+        // before the exchange: lane = 8 q' + gamma, gamma = (frame slot, c); q = q' + 8 bitrev(c),
+        // q' = (lane >> 3) ^ 4 flip[slot]
+        const int gam = lane & 7, c = gam & ((1 << stages) - 1), slot = gam >> stages;
+        const int qp = (lane >> 3) ^ (flip[slot] ? 4 : 0), sr = rot[slot];
         const int crev = stages < 2 ? c : (((c & 1) << 1) | (c >> 1));
         const int q = qp + 8 * crev;
+        T[38 * 64 + lane] = (float)q;
+        T[39 * 64 + lane] = (float)sr;
         for (int j = 0; j < 8; ++j)
             for (int cc = 0; cc < 2; ++cc)
-                T[(2 * j + cc) * 64 + lane] = 0.5f * window[2 * (LPF * j + q) + cc];
+                T[(2 * j + cc) * 64 + lane] = 0.5f * window[2 * (LPF * ((j + sr) & 7) + q) + cc];
         for (int k = 1; k < 8; ++k) {
-            double a = -2.0 * kPi * (double)(q * k) / (double)M;
+            // W_M^(q k), times W8^(sr k): register j holds block (j + sr) mod 8
+            double a = -2.0 * kPi * (double)(q * k) / (double)M - 2.0 * kPi * (double)(sr * k) / 8.0;
             T[(16 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
             T[(17 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
         }
@@ -776,7 +841,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 fpw /= 2;                           // 8 -> 4 -> 2 -> 1 groups (long hops: some waves idle)
             if (aa::wave_small_lds_dwords(cfg->n_fft, fpw, cfg->hop) <= 16384) {
                 std::vector<float> tab;
-                build_wave_small_table(cfg->n_fft, p->window_host.data(), &tab);
+                build_wave_small_table(cfg->n_fft, cfg->hop, p->window_host.data(), &tab);
                 AA_HIP(hipMalloc(&p->d_w1024_tab, tab.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_w1024_tab, tab.data(), tab.size() * sizeof(float),
                                  hipMemcpyHostToDevice));

@@ -629,6 +629,24 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_TAIL
 #define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
 #endif
+#ifndef AA_V_SPLIT
+#define AA_V_SPLIT 1       // uneven chunk runs: the remainder goes to the workgroups dispatched first
+#endif
+// The persistent workgroup's run of chunks [c0, c1).  The chunks that do not divide evenly go to the
+// workgroups dispatched FIRST: the residents of a CU finish in dispatch order even with the priority
+// rotation (64 / 66 / 66 / 68 us for the four dispatch rounds, tools/wg_finish_order.py), so the late
+// ones get the shorter runs: -1.3 % on the sustained 1024 / 256 launch against an even spread.
+__device__ __forceinline__ void chunk_run(int64_t n_chunks, int &c0, int &c1)
+{
+    if (AA_V_SPLIT) {
+        const int q = (int)(n_chunks / gridDim.x), r = (int)(n_chunks % gridDim.x), b = (int)blockIdx.x;
+        c0 = b < r ? b * (q + 1) : r * (q + 1) + (b - r) * q;
+        c1 = c0 + q + (b < r ? 1 : 0);
+    } else {
+        c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
+        c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    }
+}
 #ifndef AA_PRIO_ROTATE
 #define AA_PRIO_ROTATE 1      // 0: diagnostic builds without the rotation (tools/ab_sustained.py)
 #endif
@@ -681,8 +699,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     // This workgroup's run of chunks [c0, c1).  Everything per chunk below is 32-bit scalar
     // arithmetic on running pointers (a lone wave issues a scalar instruction only every few
     // cycles: the 64-bit multiplies of the first version cost ~450 cycles per frame).
-    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
-    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1);
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
@@ -1161,8 +1179,8 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
-    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1);
     const int max_span = (frames_per_wg - 1) * hop + 2048;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
@@ -1466,11 +1484,14 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
     // lane map before the exchange E (frame read, pass A, stages) and after it (split, store)
     const int gam = lane & 7, cA = gam & ((1 << G::STAGES) - 1);
     const int crev = G::STAGES < 2 ? cA : (((cA & 1) << 1) | (cA >> 1));
-    const int fqA = gam >> G::STAGES, qA = 8 * crev + (lane >> 3);
+    // q and the block rotation come from the plan's table: build_wave_small_table (aa_abi.cpp) relabels
+    // frame slots (q' ^ 4, block j + 1) so that the FPW frames of one read land in different banks
+    const int fqA = gam >> G::STAGES, qA = (int)tab[38 * 64 + lane], rotA = (int)tab[39 * 64 + lane];
+    (void)crev;
     const int fqB = lane / LPF, lB = lane % LPF;
 
-    const int c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
-    const int c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1);
     const int max_span = (frames_per_wg - 1) * hop + N;
     float *scrf = smem + 2 * max_span + wave * kWave256ScratchDwords;
     v2f *scr = reinterpret_cast<v2f *>(scrf);
@@ -1523,7 +1544,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         rlo[i] = (fr % FPW) * NB + k;
         rhi[i] = (fr % FPW) * NB + M - k;
     }
-    v2f *e_wr = scr + 66 * (lane & 7) + (lane >> 3);                        // + 8 k1   (E, as E1 at 1024)
+    v2f *e_wr = scr + 66 * (lane & 7) + (qA & 7);                           // + 8 k1   (E, as E1 at 1024)
     const v4f *e_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
     v2f *strip_wr = scr + fqB * SS + lB;                                    // + LPF mu
     const unsigned smem_addr = lds_addr(smem);
@@ -1547,7 +1568,10 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             const int nleft = frames_left - frames_per_wg;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
-        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * qA);
+        // register j <- block (j + rotA) mod 8: blocks are N / 2 bytes apart; one base for j = 0..6,
+        // the wrapped one for j = 7
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * qA) + (unsigned)(rotA * (N / 2));
+        const unsigned wrap7 = rotA ? (unsigned)(8 * (N / 2)) : 0u;
 
         for (int g = wave; FPW * g < nf; g += 4) {
             rotate_wave_priority(prio_step++);
@@ -1561,7 +1585,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             v[0] = small_frame_read<N, 0>(fr); v[1] = small_frame_read<N, 128>(fr);
             v[2] = small_frame_read<N, 256>(fr); v[3] = small_frame_read<N, 384>(fr);
             v[4] = small_frame_read<N, 512>(fr); v[5] = small_frame_read<N, 640>(fr);
-            v[6] = small_frame_read<N, 768>(fr); v[7] = small_frame_read<N, 896>(fr);
+            v[6] = small_frame_read<N, 768>(fr); v[7] = small_frame_read<N, 896>(fr - wrap7);
             lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)

@@ -129,6 +129,10 @@ int main(int argc, char **argv)
         sustain<0>(fpw, "full kernel (again)", sec);
         return 0;
     }
+    if (getenv("AA_ABL_ONLY")) {          // just the shipped kernel (per-workgroup clock records via AA_CLK_DUMP)
+        for (int i = 0; i < 3; ++i) run<0>(fpw, "full kernel");
+        return 0;
+    }
     for (int pc : {2, 3, 4, 5}) run<0>(fpw, "full kernel", pc);
     run<1>(fpw, "no global stores");
     run<256>(fpw, "stores hit 32 L2-resident rows");
