@@ -517,6 +517,8 @@ struct aa_stft_plan {
     // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
     bool fused_mel = false;
     bool mel_resident = false;     // 1024 kernel with the filter weights resident in registers (kLogMelR)
+    bool mfcc_fused = false;       // ... and the DCT-II behind it on the matrix cores (kMfccR)
+    float *d_dct_lane = nullptr;   // its per-lane A-operand table [tile][8][64] float4
     float *d_mel_par = nullptr;    // [kMelParTableDwords] or [kMelResidentTableDwords]
     aa::MelSched mel_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
@@ -909,6 +911,36 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 AA_HIP(hipMemcpy(p->d_mel_par, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
                 p->fused_mel = true;
             }
+            // MFCC: the DCT-II fused behind the resident mel reduction (the log-mel rows never leave
+            // the CU).  The kernel folds each row about the middle of the mel axis (the DCT-II matrix
+            // is symmetric for even coefficients, antisymmetric for odd ones), so the A-operand table
+            // of v_mfma_f32_16x16x4_f32 holds half rows: tile = (parity, half) = 16 coefficients
+            // c = 2 (16 half + i) + parity, lane = (i = lane % 16, K-group kq = lane / 16), entry
+            // [tile][S][lane][t] = d[c][16 S + 4 kq + t], orthonormal DCT-II as above; zero outside
+            // n_mfcc / n_mels / 2.
+            const char *no_fuse = std::getenv("AA_MFCC_NO_FUSE");
+            if (ok && p->mel_resident && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
+                cfg->n_mels <= aa::kMelMaxMels && cfg->n_mels % 2 == 0 && !(no_fuse && std::atoi(no_fuse) != 0) &&
+                aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384) {
+                std::vector<float> dl((size_t)aa::kMfccTableDwords, 0.0f);
+                for (int tile = 0; tile < aa::kMfccTiles; ++tile)
+                    for (int S = 0; S < 4; ++S)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int t = 0; t < 4; ++t) {
+                                const int c = 2 * (16 * (tile & 1) + (lane & 15)) + (tile >> 1);
+                                const int m = 16 * S + 4 * (lane >> 4) + t;
+                                if (c >= cfg->n_mfcc || m >= cfg->n_mels / 2)
+                                    continue;
+                                double v = std::cos(kPi * c * (2.0 * m + 1.0) / (2.0 * cfg->n_mels)) *
+                                           std::sqrt(2.0 / cfg->n_mels);
+                                if (c == 0)
+                                    v *= std::sqrt(0.5);
+                                dl[(((size_t)tile * 4 + S) * 64 + lane) * 4 + t] = (float)v;
+                            }
+                AA_HIP(hipMalloc(&p->d_dct_lane, dl.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_dct_lane, dl.data(), dl.size() * sizeof(float), hipMemcpyHostToDevice));
+                p->mfcc_fused = true;
+            }
         }
         return AA_OK;
     };
@@ -932,7 +964,7 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
             (void)hipStreamDestroy(st);
     if (p->pipe_event)
         (void)hipEventDestroy(p->pipe_event);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par,
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_dct_lane,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
@@ -1029,6 +1061,12 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         };
         if (p->cfg.output == AA_OUT_LOGMEL)
             return mel_stage(frame_begin, nf, out_dev);
+        if (p->mfcc_fused) {
+            AA_HIP(aa::launch_wave1024(aa::kMfccR, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf,
+                                       p->cfg.hop, p->frames_per_wg, p->log_floor, st, p->d_mel_par,
+                                       &p->mel_sched, p->d_dct_lane, p->cfg.n_mfcc));
+            return AA_OK;
+        }
         // log-mel rows are small (n_mels floats): one slab of up to 2^18 frames (<= 134 MB) so the
         // DCT GEMM runs as one large launch; the buffer grows on first use
         const int64_t slab = std::min<int64_t>(nf, kMfccSlab);

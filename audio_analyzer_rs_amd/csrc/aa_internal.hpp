@@ -12,7 +12,9 @@ int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
 
 // Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
 // the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
-enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5 };
+// kMfccR: kLogMelR + the DCT-II fused behind it (1024 kernel only): the log-mel rows of 16 frames stay
+// in LDS and go through v_mfma_f32_16x16x4_f32 (see stft_wave1024_kernel).
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5, kMfccR = 6 };
 
 // ---- fused mel reduction (wave kernels, kLogMel) ------------------------------------
 // The filterbank is triangular: 98 % zeros, every bin feeds at most two filters, so the fused
@@ -31,6 +33,16 @@ constexpr int kMelParDwords = 6;
 constexpr int kMelParTableDwords = (kMelMaxMels + 1) * kMelParDwords + 2;   // 776, keeps 16-byte size
 constexpr int kMelStageDwords = 256;                // per wave: mel values of up to two frames
 constexpr int kMelLdsDwords = kMelParTableDwords + 4 * kMelStageDwords;
+// kMfccR: log-mel rows of two chunks (16 frames) in LDS, folded about the middle of the mel axis
+// (u = L[m] + L[M-1-m] in floats 0..63, v = L[m] - L[M-1-m] in floats 64..127; the DCT-II matrix is
+// symmetric / antisymmetric there), row stride 132 floats (the B-operand reads of the MFMA - 16 frames
+// x 4 K-groups, 16 bytes each - then spread over all 64 banks).  The DCT matrix comes as a per-lane
+// table [tile][4][64] float4: tile = (parity, half) = 16 coefficients c = 2 (16 half + i) + parity,
+// K ordered m = 16 S + 4 (lane / 16) + t: 4 tiles = up to 64 coefficients, n_mels even and <= 128.
+constexpr int kMfccRowStride = 132;
+constexpr int kMfccLdsDwords = 16 * kMfccRowStride;
+constexpr int kMfccTiles = 4;
+constexpr int kMfccTableDwords = kMfccTiles * 4 * 64 * 4;
 struct MelSched {
     int n_mels = 0;
     int n_groups = 0;
@@ -56,21 +68,23 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
 // LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
 // of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
-inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, bool mel = false)
+// mel: 0 none, 1 fused mel reduction (kLogMel / kLogMelR), 2 fused MFCC (kMfccR)
+inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int mel = 0)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
-    return 2 * span + 4 * kWave1024ScratchDwords + (mel ? kMelLdsDwords : 0);
+    return 2 * span + 4 * kWave1024ScratchDwords + (mel == 2 ? kMfccLdsDwords : mel ? kMelLdsDwords : 0);
 }
-inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, bool mel = false)
+inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int mel = 0)
 {
     return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop, mel);
 }
 
 // mel_par / sched are used by kLogMel only (null / nullptr otherwise).
+// dct_tab / n_mfcc: kMfccR only (kMfccTableDwords floats; n_mfcc <= 16 kMfccTiles).
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,
-                           const MelSched *sched = nullptr);
+                           const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0);
 
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;

@@ -82,7 +82,7 @@ __device__ __forceinline__ float bin_from_power(float p, float log_floor)
 {
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR)
         return p;
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
 }
@@ -93,7 +93,7 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
     float p = re * re + im * im;
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
@@ -489,7 +489,7 @@ __device__ __forceinline__ void mel_lds_wait_step(v2f (&c)[4])
 }
 template <int NS, int F>
 __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident<NS> &mr,
-                                                    const MelSched &sch, float *stage)
+                                                    const MelSched &sch, float *stage, int stride_b = 128)
 {
     constexpr unsigned kRowB = 513 * 4;              // F == 2 (1024): row b = row a + 513 floats
     constexpr int LPS = 2 * F;                       // ds_read2_b32 per step
@@ -579,7 +579,7 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
             if ((lane >> (6 - pl)) == 0 && mel < kMelMaxMels) {
                 stage[mel] = acc_a;
                 if (F == 2)
-                    stage[128 + mel] = acc_b;
+                    stage[stride_b + mel] = acc_b;
             }
             acc_a = 0.0f;
             acc_b = 0.0f;
@@ -685,10 +685,13 @@ __device__ __forceinline__ void rotate_wave_priority(int step)
 // 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80), 1024 no
 // priority rotation.
 template <int OUT, int ABL = 0, bool WIDE = false>
-__global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
+__global__ __launch_bounds__(kWave1024Threads)
+__attribute__((amdgpu_waves_per_eu(OUT == kMfccR ? 3 : 1)))      // kMfccR: stay within 168 VGPRs (3 waves per SIMD)
+void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor, const float *__restrict__ mel_par, MelSched sch)
+    float log_floor, const float *__restrict__ mel_par, MelSched sch, const float *__restrict__ dct_tab,
+    int n_mfcc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
-    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR;
     constexpr bool PAIR = AA_V_PAIR && WIDE && !MEL && OUT != kComplex;
     // global stores a wave issues for its two rows of a full 8-frame chunk (every one is issued by
     // every wave: the lane masks never empty the wave) - the count the chunk-top wait leaves in flight
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                                        : !WIDE         ? 2 * 9                      // 9 dwords per row
                                        : PAIR          ? 5                          // 4 dwordx4 + 1 dwordx2 per row PAIR
                                                        : 2 * 3;                     // 2 dwordx4 + 1 dword per row
-    const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
+    const int COLS = (OUT == kComplex) ? 2 * NB : OUT == kMfccR ? n_mfcc : MEL ? sch.n_mels : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
     float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
@@ -726,8 +729,9 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
     MelResident<kMelResidentSteps1024> mres;
-    if (OUT == kLogMelR)
+    if (OUT == kLogMelR || OUT == kMfccR)
         mel_resident_load(mres, mel_par);
+    float *lm = melpar;                      // kMfccR: log-mel rows of two chunks, [16][kMfccRowStride]
 
     // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
     // (wave w moves the 1 KiB pieces w, w+4, ..)
@@ -774,8 +778,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
         // The DMA loads of this chunk were issued before the previous chunk's row stores, and
         // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
-        if ((ABL & 64) || c == c0 || frames_per_wg != 8)
-            wait_vmcnt_le<0>();
+        if ((ABL & 64) || c == c0 || frames_per_wg != 8 || OUT == kMfccR)
+            wait_vmcnt_le<0>();              // (kMfccR: the few DCT stores of a chunk pair are long done)
         else if (MEL && sch.n_mels > 64)
             wait_vmcnt_le<4>();                                  // 2 dword stores per mel row, 2 rows
         else if (MEL)
@@ -1097,6 +1101,80 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave1024_kernel(
                     __builtin_amdgcn_wave_barrier();
                     mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, melstage);
                     mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
+                } else if (OUT == kMfccR) {
+                    // mel values of the two frames -> rows 8 (chunk parity) + t of the log-mel block,
+                    // 10 log10(max(., floor)) in place; columns past n_mels are zero (their DCT
+                    // weights are zero too, but 0 x garbage could be a NaN)
+                    __builtin_amdgcn_wave_barrier();
+                    float *rows = lm + (8 * ((c - c0) & 1) + ta) * kMfccRowStride;
+                    // (rows 0..7 were read by the DCT at the top of this chunk: every wave is past it -
+                    // the barrier below the DCT phase)
+                    mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, rows, 4 * kMfccRowStride);
+                    __builtin_amdgcn_wave_barrier();
+                    // u[m] = L[m] + L[M-1-m], v[m] = L[m] - L[M-1-m] (m < M/2): the DCT-II matrix is
+                    // symmetric (even coefficients) / antisymmetric (odd) about the middle of the mel
+                    // axis, so the contraction is two of half the length
+                    const int half_m = sch.n_mels >> 1;
+#pragma unroll
+                    for (int ff = 0; ff < 2; ++ff) {
+                        float *r = rows + ff * 4 * kMfccRowStride;
+                        const int mirror = lane < half_m ? sch.n_mels - 1 - lane : 0;
+                        const float la = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[lane], log_floor));
+                        const float lb = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[mirror], log_floor));
+                        __builtin_amdgcn_wave_barrier();
+                        r[lane] = lane < half_m ? la + lb : 0.0f;
+                        r[64 + lane] = lane < half_m ? la - lb : 0.0f;
+                    }
+                }
+            }
+            if (OUT == kMfccR && (((c - c0) & 1) || c + 1 == c1)) {
+                // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores.  Wave w owns a
+                // tile of 16 coefficients of one parity (w >> 1), c = 2 (16 (w & 1) + i) + parity:
+                // D[i][frame] = sum_{m < 64} Dm[c][m] u|v[frame][m] = 16 v_mfma_f32_16x16x4_f32 (an exact
+                // f32 fma chain per output).  A operand: lane = (i = lane % 16, K-group kq = lane / 16),
+                // 4 dwordx4 of the plan's table (L2 resident), fetched BEFORE the barrier so that their
+                // latency overlaps the wait for the other waves' rows; B operand: lane = (kq, frame
+                // j = lane % 16), 4 ds_read_b128 of row j.  K order m = 16 S + 4 kq + t for step 4 S + t
+                // (any order will do as long as A and B agree).  No barrier behind the phase: the rows
+                // are rewritten at the END of the next chunk, which starts with a barrier of its own.
+                // (Measured alternatives: the phase behind the NEXT chunk-top barrier, with the A operand
+                // fetched before that barrier or carried over from the end of this chunk, costs 20+
+                // VGPR spills - the top of the chunk loop is where the register allocator keeps most
+                // alive - and runs at 128 us against 99.)
+                const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + lane;
+                const v4f a0 = at[0], a1 = at[64], a2 = at[128], a3 = at[192];
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+                const v4f *bt = reinterpret_cast<const v4f *>(lm + (lane & 15) * kMfccRowStride + 64 * (wave >> 1) +
+                                                            4 * (lane >> 4));
+                const v4f b0 = bt[0], b1 = bt[4], b2 = bt[8], b3 = bt[12];
+                v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, b3.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, b3.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b2.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, b3.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b2.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, b3.w, acc1, 0, 0, 0);
+                const v4f d = acc0 + acc1;
+                // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
+                const int j = lane & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (lane >> 4)) + (wave >> 1);
+                const int have = ((c - c0) & 1) ? 8 + nf : nf;         // valid rows (a lone last chunk: rows 0..7)
+                float *orow = out_chunk - (((c - c0) & 1) ? 8 * COLS : 0) + j * COLS + coef0;
+                if (j < have) {
+                    if (coef0 + 0 < n_mfcc) orow[0] = d.x;
+                    if (coef0 + 2 < n_mfcc) orow[2] = d.y;
+                    if (coef0 + 4 < n_mfcc) orow[4] = d.z;
+                    if (coef0 + 6 < n_mfcc) orow[6] = d.w;
                 }
             }
         } else {
@@ -2142,10 +2220,10 @@ template <int K>
 static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
-                                       const MelSched &sch)
+                                       const MelSched &sch, const float *dct_tab = nullptr, int n_mfcc = 0)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kMfccR ? 2 : (K == kLogMel || K == kLogMelR) ? 1 : 0);
     static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
     static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
@@ -2155,23 +2233,27 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
     const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
     if (wide)
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, true>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc);
     else
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc);
     return hipGetLastError();
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched)
+                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched,
+                           const float *dct_tab, int n_mfcc)
 {
     if (n_frames <= 0)
         return hipSuccess;
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
-    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
+    if ((out_kind == kLogMelR || out_kind == kMfccR) &&
+        (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
+        return hipErrorInvalidValue;
+    if (out_kind == kMfccR && (!dct_tab || n_mfcc < 1 || n_mfcc > 16 * kMfccTiles || sch.n_mels > kMelMaxMels))
         return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
@@ -2188,6 +2270,8 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
         return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kLogMelR:
         return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+    case kMfccR:
+        return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, dct_tab, n_mfcc);
     default:
         return hipErrorInvalidValue;
     }

@@ -874,3 +874,38 @@ def test_mag_edge_values(aa, torch_mod, n):
             assert np.isnan(got[1]).all()
         keep = [0, 2, 3, 4, 5, 6, 7]
         assert np.array_equal(got[keep], clean[keep])
+
+
+# ------------------------------------------------------ fused MFCC (DCT on the matrix cores) --
+@pytest.mark.parametrize("n_mels,n_mfcc", [(128, 40), (128, 13), (128, 64), (80, 20), (40, 40), (64, 17), (126, 33), (65, 12)])
+def test_fused_mfcc_matches_truth_and_unfused_path(aa, oracle_mod, torch_mod, monkeypatch, n_mels, n_mfcc):
+    """BASELINE configs[4] at 1024 / 256: the DCT-II runs inside the STFT kernel (log-mel rows of 16
+    frames stay in LDS, v_mfma_f32_16x16x4_f32).  Every row of ragged sizes - one frame, a lone last
+    chunk, odd and even chunk counts - against the float64 definition and against the two-kernel path
+    (AA_MFCC_NO_FUSE=1: log-mel slab + GEMM)."""
+    sr, n, hop = 48000, 1024, 256
+    tr = oracle_mod.truth
+    dct = tr.dct2_ortho(n_mfcc, n_mels)
+    fb = tr.mel_filterbank(sr, n, n_mels)
+    kw = dict(output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc)
+    fused = aa.Stft(n, hop, **kw)
+    monkeypatch.setenv("AA_MFCC_NO_FUSE", "1")
+    plain = aa.Stft(n, hop, **kw)
+    monkeypatch.delenv("AA_MFCC_NO_FUSE")
+    rng = np.random.default_rng(n_mels * 100 + n_mfcc)
+    for nf in (1, 2, 7, 8, 9, 15, 16, 17, 24, 25, 1000, 4099):
+        L = n + (nf - 1) * hop
+        x = (aa.signals.synth_corpus(nf, L) + 1e-3 * rng.standard_normal(L)).astype(np.float32)
+        xd = torch_mod.from_numpy(x).cuda()
+        buf = torch_mod.full((nf * n_mfcc + 64,), float("nan"), device="cuda")
+        got = fused.execute_device(xd, 0, nf, out=buf[:nf * n_mfcc].view(nf, n_mfcc))
+        torch_mod.cuda.synchronize()
+        assert torch_mod.isnan(buf[nf * n_mfcc:]).all(), "wrote past the slab"
+        got = got.cpu().numpy()
+        ref2 = plain(xd).cpu().numpy()
+        P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+        Lm = 10.0 * np.log10(np.maximum(P @ fb.T, 1e-10))
+        ref = Lm @ dct.T
+        assert got.shape == ref.shape == (nf, n_mfcc) and np.isfinite(got).all()
+        assert nerr(got, ref).max() < 1e-5, (nf, nerr(got, ref).max())
+        assert nerr(got, ref2.astype(np.float64)).max() < 1e-5

@@ -31,7 +31,7 @@ double run(int fpw, const char *name, int force_per_cu = 0)
         hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, true>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
-                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched());
+                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched(), (const float *)nullptr, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -80,7 +80,7 @@ void sustain(int fpw, const char *name, double seconds)
         hipEventRecord(e0, 0);
         for (int i = 0; i < 500; ++i)
             hipLaunchKernelGGL((aa::stft_wave1024_kernel<aa::kMag, ABL, WIDE>), dim3(grid), dim3(256), lds, 0, dx, dout, dtab,
-                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched());
+                               (int64_t)0, n_frames, hop, fpw, chunks, 1e-10f, (const float *)nullptr, aa::MelSched(), (const float *)nullptr, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
