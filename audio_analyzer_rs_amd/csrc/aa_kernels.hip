@@ -1115,15 +1115,17 @@ void stft_wave1024_kernel(
                     // symmetric (even coefficients) / antisymmetric (odd) about the middle of the mel
                     // axis, so the contraction is two of half the length
                     const int half_m = sch.n_mels >> 1;
+                    int lf = lane;
+                    asm volatile("" : "+v"(lf));                        // (opaque: see the DCT phase)
 #pragma unroll
                     for (int ff = 0; ff < 2; ++ff) {
                         float *r = rows + ff * 4 * kMfccRowStride;
-                        const int mirror = lane < half_m ? sch.n_mels - 1 - lane : 0;
-                        const float la = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[lane], log_floor));
+                        const int mirror = lf < half_m ? sch.n_mels - 1 - lf : 0;
+                        const float la = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[lf], log_floor));
                         const float lb = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[mirror], log_floor));
                         __builtin_amdgcn_wave_barrier();
-                        r[lane] = lane < half_m ? la + lb : 0.0f;
-                        r[64 + lane] = lane < half_m ? la - lb : 0.0f;
+                        r[lf] = lf < half_m ? la + lb : 0.0f;
+                        r[64 + lf] = lf < half_m ? la - lb : 0.0f;
                     }
                 }
             }
@@ -1141,12 +1143,16 @@ void stft_wave1024_kernel(
                 // fetched before that barrier or carried over from the end of this chunk, costs 20+
                 // VGPR spills - the top of the chunk loop is where the register allocator keeps most
                 // alive - and runs at 128 us against 99.)
-                const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + lane;
+                // (the lane index goes through an opaque copy: otherwise the per-lane addresses below are
+                // loop invariant, get hoisted out of the chunk loop and stay live through the FFT phases)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + ln;
                 const v4f a0 = at[0], a1 = at[64], a2 = at[128], a3 = at[192];
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_s_barrier();
-                const v4f *bt = reinterpret_cast<const v4f *>(lm + (lane & 15) * kMfccRowStride + 64 * (wave >> 1) +
-                                                            4 * (lane >> 4));
+                const v4f *bt = reinterpret_cast<const v4f *>(lm + (ln & 15) * kMfccRowStride + 64 * (wave >> 1) +
+                                                            4 * (ln >> 4));
                 const v4f b0 = bt[0], b1 = bt[4], b2 = bt[8], b3 = bt[12];
                 v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
@@ -1167,7 +1173,7 @@ void stft_wave1024_kernel(
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, b3.w, acc1, 0, 0, 0);
                 const v4f d = acc0 + acc1;
                 // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
-                const int j = lane & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (lane >> 4)) + (wave >> 1);
+                const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
                 const int have = ((c - c0) & 1) ? 8 + nf : nf;         // valid rows (a lone last chunk: rows 0..7)
                 float *orow = out_chunk - (((c - c0) & 1) ? 8 * COLS : 0) + j * COLS + coef0;
                 if (j < have) {
