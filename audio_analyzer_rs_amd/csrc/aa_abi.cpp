@@ -415,7 +415,8 @@ void build_wave_small_table(int n_fft, int hop, const float *window, std::vector
     // (flip, rot) per frame slot: exhaustive over the 4^FPW assignments (<= 65536), fewest passes,
     // ties to the plain map
     int flip[8] = {0}, rot[8] = {0}, best = small_read_passes(n_fft, hop, stages, FPW, LPF, flip, rot);
-    if (best > 16) {
+    const char *plain = std::getenv("AA_SMALL_PLAIN_MAP");      // diagnostic: the unrelabelled map (PMC before / after)
+    if (best > 16 && !(plain && std::atoi(plain) != 0)) {
         int bf[8] = {0}, br[8] = {0};
         for (int code = 1; code < (1 << (2 * FPW)) && best > 16; ++code) {
             int f2[8], r2[8];
