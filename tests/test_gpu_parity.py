@@ -909,3 +909,36 @@ def test_fused_mfcc_matches_truth_and_unfused_path(aa, oracle_mod, torch_mod, mo
         assert got.shape == ref.shape == (nf, n_mfcc) and np.isfinite(got).all()
         assert nerr(got, ref).max() < 1e-5, (nf, nerr(got, ref).max())
         assert nerr(got, ref2.astype(np.float64)).max() < 1e-5
+
+
+# ------------------------------ every row of a launch much larger than the persistent grid --
+@pytest.mark.parametrize("n,hop", [(1024, 256), (2048, 512), (256, 64)])
+@pytest.mark.parametrize("output", ["mag", "complex", "power", "logpower"])
+def test_every_row_of_a_many_chunk_launch(aa, oracle_mod, torch_mod, n, hop, output):
+    """Frames >> workgroups x frames per chunk and a ragged tail, EVERY row against the float64 truth:
+    the double-buffered LDS-DMA of the wave kernels is released by a counted `s_waitcnt vmcnt(N)`
+    (N = the stores of the previous chunk, derived from the epilogue at compile time); a wrong count
+    would show as an occasional row computed from a half-landed sample buffer, which spot checks at
+    full size do not reliably see (ADVICE, round 1)."""
+    nf = {1024: 40011, 2048: 20003, 256: 130007}[n]          # 4.9 / 4.9 / 2 chunks per workgroup, ragged
+    x = aa.signals.synth_corpus(17, n + (nf - 1) * hop)
+    plan = aa.Stft(n, hop, output=output)
+    xd = torch_mod.from_numpy(x).cuda()
+    for rep in range(3):                                     # back to back: stores of launch i in flight under launch i+1
+        got = plan(xd)
+    got = got.cpu().numpy()
+    spec = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
+    if output == "complex":
+        ref = spec
+    elif output == "mag":
+        ref = np.abs(spec)
+    else:
+        ref = np.abs(spec) ** 2
+    if output == "logpower":
+        # linear-domain criterion after undoing the log (as for log-mel), floor 1e-10
+        got = 10.0 ** (got.astype(np.float64) / 10.0)
+        ref = np.maximum(ref, 1e-10)
+    assert got.shape[0] == nf
+    tol = TOL_VS_TRUTH if output in ("mag", "complex") else 2e-5
+    e = nerr(got, ref)
+    assert e.max() <= tol, (int(np.argmax(e)), float(e.max()))
