@@ -69,6 +69,39 @@ __global__ __launch_bounds__(256) void k_mfma(float *out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// streams of one packed instruction (8 independent chains, 64 per iteration): energy per instruction
+template <int OP>
+__global__ __launch_bounds__(256) void k_stream(float *out, int iters)
+{
+    v2f p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        p[j] = v2f{1.0f + (float)(threadIdx.x + j) * 1e-6f, 1.0f - (float)(threadIdx.x + j) * 1e-6f};
+    v2f b = {1.0000001f, 0.9999999f}, c = {1e-9f, -1e-9f};
+    for (int i = 0; i < iters; ++i) {
+#define ONE(INS) asm volatile(INS : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(b), "v"(c))
+#define R8(X) X X X X X X X X
+        if (OP == 0)
+            ONE(R8("v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %1, %1, %9\n v_pk_add_f32 %2, %2, %9\n v_pk_add_f32 %3, %3, %9\n v_pk_add_f32 %4, %4, %9\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %9\n v_pk_add_f32 %7, %7, %9\n"));
+        else if (OP == 1)
+            ONE(R8("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"));
+        else if (OP == 2)
+            ONE(R8("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"));
+        else if (OP == 3)   // fma whose addend is another live register (as in a scaled butterfly)
+            ONE(R8("v_pk_fma_f32 %0, %1, %8, %0\n v_pk_fma_f32 %1, %2, %8, %1\n v_pk_fma_f32 %2, %3, %8, %2\n v_pk_fma_f32 %3, %4, %8, %3\n v_pk_fma_f32 %4, %5, %8, %4\n v_pk_fma_f32 %5, %6, %8, %5\n v_pk_fma_f32 %6, %7, %8, %6\n v_pk_fma_f32 %7, %0, %8, %7\n"));
+        else
+            ONE(R8("v_pk_add_f32 %0, %1, %0\n v_pk_add_f32 %1, %2, %1\n v_pk_add_f32 %2, %3, %2\n v_pk_add_f32 %3, %4, %3\n v_pk_add_f32 %4, %5, %4\n v_pk_add_f32 %5, %6, %5\n v_pk_add_f32 %6, %7, %6\n v_pk_add_f32 %7, %0, %7\n"));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)                 // keep the values near 1 (not counted: 8 of 72)
+            p[j] = p[j] * v2f{0.5f, 0.5f} + v2f{0.5f, 0.5f};
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        acc += p[j].x + p[j].y;
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 template <typename K>
 static void sustain(K kern, const char *name, float *out, int iters, int passes_per_iter, double seconds)
 {
@@ -104,5 +137,11 @@ int main(int argc, char **argv)
     sustain(k_valu, "pk_dft8 (28 packed f32 instructions)", out, 2000, 2, sec);
     sustain(k_mfma, "16 x v_mfma_f32_16x16x4_f32", out, 2000, 1, sec);
     sustain(k_valu, "pk_dft8 (again)", out, 2000, 2, sec);
+    // "pass" = 64 instructions here
+    sustain(k_stream<0>, "64 x v_pk_add_f32 (reg + const)", out, 2000, 1, sec);
+    sustain(k_stream<4>, "64 x v_pk_add_f32 (reg + reg)", out, 2000, 1, sec);
+    sustain(k_stream<1>, "64 x v_pk_mul_f32", out, 2000, 1, sec);
+    sustain(k_stream<2>, "64 x v_pk_fma_f32 (reg, const, const)", out, 2000, 1, sec);
+    sustain(k_stream<3>, "64 x v_pk_fma_f32 (reg, const, reg)", out, 2000, 1, sec);
     return 0;
 }
