@@ -463,8 +463,13 @@ void build_wave_small_table(int n_fft, int hop, const float *window, std::vector
             T[(31 + 2 * st) * 64 + lane] = (float)std::sin(a);
         }
         for (int i = 0; i < 5; ++i) {
+            // split twiddles -i W_N^k: 128 / 512 spread the (k, M-k) pairs of the wave's frames over the
+            // lanes (pair p = lane + 64 i); 256 keeps the pairs of a frame in its own 16 lanes
+            // (k = lane % 16 + 16 i, i < 4: the partner comes by DPP, see the kernel)
             const int p = lane + 64 * i;
-            const int kk = p < FPW * PPF ? p % PPF : 0;
+            int kk = p < FPW * PPF ? p % PPF : 0;
+            if (LPF == 16)
+                kk = i < 4 ? (lane & 15) + 16 * i : 0;
             double th = 2.0 * kPi * (double)kk / (double)n_fft;
             T[(40 + 2 * i) * 64 + lane] = (float)(-std::sin(th));
             T[(41 + 2 * i) * 64 + lane] = (float)(-std::cos(th));

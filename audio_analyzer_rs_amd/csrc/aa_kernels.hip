@@ -1701,6 +1701,53 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             // ---- pass C: lane l of its frame ends with Z[l + LPF mu] in register mu ----
             pk_dft8(v);
 
+            float *grp = out_chunk + (FPW * g) * COLS;   // first row of the group
+            if (LPF == 16) {
+                // ---- 256: the split partner without LDS.  Lane l of a frame (= one DPP row) holds
+                // Z[l + 16 mu]; the partner of k = l + 16 mu (mu < 4) is Z[128 - k] = register 7 - mu
+                // of lane 16 - l: a row_mirror followed by a row_shr:1 whose out-of-range lane 0 keeps
+                // its `old` operand - lane 0's partner is its own register 8 - mu (Z[128] := Z[0]).
+                v2f prt[4];
+                hazard_fence(v);   // packed asm -> DPP read
+#pragma unroll
+                for (int mu = 0; mu < 4; ++mu) {
+                    const v2f own = v[mu == 0 ? 0 : 8 - mu], src = v[7 - mu];
+                    const float mx = dpp_update<0x140, 0xF>(src.x, src.x), my = dpp_update<0x140, 0xF>(src.y, src.y);
+                    prt[mu] = v2f{dpp_update<0x111, 0xF>(own.x, mx), dpp_update<0x111, 0xF>(own.y, my)};
+                }
+                const bool live = fqB < nvalid;
+                float mk[4], mm[4];
+#pragma unroll
+                for (int mu = 0; mu < 4; ++mu) {
+                    const v2f e = pk_add_conj(v[mu], prt[mu]), o = pk_sub_conj(v[mu], prt[mu]);
+                    const v2f tt = pk_cmul(o, tws[mu]);
+                    const v2f xk = e + tt, xm = e - tt;        // X[128-k] = conj(xm)
+                    const int k = lB + 16 * mu;
+                    if (OUT == kComplex) {
+                        if (live) {
+                            reinterpret_cast<v2f *>(grp)[fqB * NB + k] = xk;
+                            reinterpret_cast<v2f *>(grp)[fqB * NB + M - k] = v2f{xm.x, -xm.y};
+                        }
+                    } else {
+                        mk[mu] = bin_value<OUT>(xk.x, xk.y, log_floor);
+                        mm[mu] = bin_value<OUT>(xm.x, xm.y, log_floor);
+                    }
+                }
+                // bin 64 = Z[64], its own partner: lane 0 of the frame, register 4
+                if (OUT == kComplex) {
+                    if (live && lB == 0)
+                        reinterpret_cast<v2f *>(grp)[fqB * NB + 64] = v2f{2.0f * v[4].x, -2.0f * v[4].y};
+                } else {
+                    float *img = scrf + fqB * NB;
+#pragma unroll
+                    for (int mu = 0; mu < 4; ++mu) {
+                        img[lB + 16 * mu] = mk[mu];
+                        img[M - lB - 16 * mu] = mm[mu];
+                    }
+                    if (lB == 0)
+                        img[64] = bin_value<OUT>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+                }
+            } else {
             // ---- strip: Z of the FPW frames, Z[M] := Z[0] ----
 #pragma unroll
             for (int mu = 0; mu < 8; ++mu)
@@ -1715,7 +1762,6 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
                 zb[i] = scr[pb[i]];
             }
             __builtin_amdgcn_wave_barrier();
-            float *grp = out_chunk + (FPW * g) * COLS;   // first row of the group
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 v2f e = pk_add_conj(za[i], zb[i]), o = pk_sub_conj(za[i], zb[i]);
@@ -1736,6 +1782,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
                     }
                 }
             }
+            }   // LPF != 16
             if (OUT != kComplex) {
                 __builtin_amdgcn_wave_barrier();
                 if (WIDE && nvalid == FPW && G::ROW_FLOATS % 4 == 0) {
