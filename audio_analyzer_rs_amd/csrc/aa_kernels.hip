@@ -70,6 +70,19 @@ __device__ __forceinline__ void wait_vmcnt_le()
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// Row stores: nontemporal (the rows are written once and not read by this kernel).  AA_V_STORE = 1
+// (experiments): plain stores.
+#ifndef AA_V_STORE
+#define AA_V_STORE 0
+#endif
+template <typename T>
+__device__ __forceinline__ void row_store(T v, T *p)
+{
+    if (AA_V_STORE == 1)
+        *p = v;
+    else
+        __builtin_nontemporal_store(v, p);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
@@ -629,6 +642,9 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_TAIL
 #define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
 #endif
+#ifndef AA_V_ILV
+#define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
+#endif
 #ifndef AA_V_SPLIT
 #define AA_V_SPLIT 1       // uneven chunk runs: the remainder goes to the workgroups dispatched first
 #endif
@@ -704,6 +720,16 @@ void stft_wave1024_kernel(
     // cycles: the 64-bit multiplies of the first version cost ~450 cycles per frame).
     int c0, c1;
     chunk_run(n_chunks, c0, c1);
+    // AA_V_ILV: interleaved chunks instead of one contiguous run per workgroup - at any time the
+    // resident workgroups work inside one window of gridDim.x chunks (8 MB of samples, 17 / 34 MB of
+    // rows), XCD x (= blockIdx % 8) on the x-th eighth of it so that neighbouring chunks share an L2:
+    // workgroup b takes chunks (b % 8) G/8 + b / 8 + i G.
+    const int cstep = AA_V_ILV ? (int)gridDim.x : 1;
+    if (AA_V_ILV) {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x;
+        c0 = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+        c1 = (int)n_chunks;
+    }
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
@@ -720,7 +746,8 @@ void stft_wave1024_kernel(
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
     float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
     int frames_left = (int)(n_frames - first_frame);                            // from chunk c on
-    const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
+    const int src_stride = frames_per_wg * hop * cstep, out_stride = frames_per_wg * COLS * cstep;
+    const int frames_step = frames_per_wg * cstep;
     // fused mel: per-mel triangle parameters in LDS behind the scratch areas (visible after the
     // first chunk-top barrier)
     float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
@@ -773,12 +800,13 @@ void stft_wave1024_kernel(
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
     const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
-    for (int c = c0; c < c1; ++c) {
-        const int cur = (int)(c - c0) & 1;
+    int it = 0;
+    for (int c = c0; c < c1; c += cstep, ++it) {
+        const int cur = it & 1;
         // The DMA loads of this chunk were issued before the previous chunk's row stores, and
         // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
-        if ((ABL & 64) || c == c0 || frames_per_wg != 8 || OUT == kMfccR)
+        if ((ABL & 64) || it == 0 || frames_per_wg != 8 || OUT == kMfccR)
             wait_vmcnt_le<0>();              // (kMfccR: the few DCT stores of a chunk pair are long done)
         else if (MEL && sch.n_mels > 64)
             wait_vmcnt_le<4>();                                  // 2 dword stores per mel row, 2 rows
@@ -788,12 +816,12 @@ void stft_wave1024_kernel(
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        const int prio_step = (int)(blockIdx.x >> 8) + 4 * (c - c0);   // dispatch round + quarter chunks
+        const int prio_step = (int)(blockIdx.x >> 8) + 4 * it;   // dispatch round + quarter chunks
         if (!(ABL & 1024))
             rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
-        if (c + 1 < c1 && !(ABL & 8)) {
-            const int nleft = frames_left - frames_per_wg;
+        if (c + cstep < c1 && !(ABL & 8)) {
+            const int nleft = frames_left - frames_step;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
         const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
@@ -918,10 +946,10 @@ void stft_wave1024_kernel(
                     __builtin_amdgcn_wave_barrier();
                     if (valid) {
                         v4f *gw4 = reinterpret_cast<v4f *>(row - 2 * shc) + shc + lane;
-                        __builtin_nontemporal_store(q0, gw4);
-                        __builtin_nontemporal_store(q1, gw4 + 64);
-                        __builtin_nontemporal_store(q2, gw4 + 128);
-                        __builtin_nontemporal_store(q3, gw4 + 192);
+                        row_store(q0, gw4);
+                        row_store(q1, gw4 + 64);
+                        row_store(q2, gw4 + 128);
+                        row_store(q3, gw4 + 192);
                         if (lane == 0)
                             reinterpret_cast<v2f *>(row)[shc ? 0 : 512] = edge;
                     }
@@ -1001,10 +1029,10 @@ void stft_wave1024_kernel(
                         const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
                         __builtin_amdgcn_wave_barrier();
                         v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
-                        __builtin_nontemporal_store(q0, gw4);
-                        __builtin_nontemporal_store(q1, gw4 + 64);
-                        __builtin_nontemporal_store(q2, gw4 + 128);
-                        __builtin_nontemporal_store(q3, gw4 + 192);
+                        row_store(q0, gw4);
+                        row_store(q1, gw4 + 64);
+                        row_store(q2, gw4 + 128);
+                        row_store(q3, gw4 + 192);
                         if (lane == 0)
                             *reinterpret_cast<v2f *>(gw + eo) = edge;
                     } else {
@@ -1014,9 +1042,9 @@ void stft_wave1024_kernel(
                         const int hi = lane < 4 ? lane : 508 + lane;
                         const float hv = lw[lane < 8 ? hi : 0];
                         __builtin_amdgcn_wave_barrier();
-                        __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                        row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
                         if (lane < 63)
-                            __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                            row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
                         if ((unsigned)(sh2 - tail_lo) <= tail_span)
                             gw[hi] = hv;
                     }
@@ -1044,9 +1072,9 @@ void stft_wave1024_kernel(
                 const float hv = lw[lane < 8 ? hi : 0];
                 __builtin_amdgcn_wave_barrier();
                 if (valid) {
-                    __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                    row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
                     if (lane < 63)
-                        __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                        row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
                     // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
                     const bool ok = AA_V_TAIL ? (unsigned)(sh - tail_lo) <= tail_span
                                               : lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
@@ -1106,7 +1134,7 @@ void stft_wave1024_kernel(
                     // 10 log10(max(., floor)) in place; columns past n_mels are zero (their DCT
                     // weights are zero too, but 0 x garbage could be a NaN)
                     __builtin_amdgcn_wave_barrier();
-                    float *rows = lm + (8 * ((c - c0) & 1) + ta) * kMfccRowStride;
+                    float *rows = lm + (8 * (it & 1) + ta) * kMfccRowStride;
                     // (rows 0..7 were read by the DCT at the top of this chunk: every wave is past it -
                     // the barrier below the DCT phase)
                     mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, rows, 4 * kMfccRowStride);
@@ -1129,7 +1157,7 @@ void stft_wave1024_kernel(
                     }
                 }
             }
-            if (OUT == kMfccR && (((c - c0) & 1) || c + 1 == c1)) {
+            if (OUT == kMfccR && ((it & 1) || c + cstep >= c1)) {
                 // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores.  Wave w owns a
                 // tile of 16 coefficients of one parity (w >> 1), c = 2 (16 (w & 1) + i) + parity:
                 // D[i][frame] = sum_{m < 64} Dm[c][m] u|v[frame][m] = 16 v_mfma_f32_16x16x4_f32 (an exact
@@ -1174,8 +1202,10 @@ void stft_wave1024_kernel(
                 const v4f d = acc0 + acc1;
                 // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
                 const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
-                const int have = ((c - c0) & 1) ? 8 + nf : nf;         // valid rows (a lone last chunk: rows 0..7)
-                float *orow = out_chunk - (((c - c0) & 1) ? 8 * COLS : 0) + j * COLS + coef0;
+                const int have = (it & 1) ? 8 + nf : nf;               // valid rows (a lone last chunk: rows 0..7)
+                // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's
+                float *orow = ((it & 1) ? (j < 8 ? out_chunk - out_stride + j * COLS : out_chunk + (j - 8) * COLS)
+                                        : out_chunk + j * COLS) + coef0;
                 if (j < have) {
                     if (coef0 + 0 < n_mfcc) orow[0] = d.x;
                     if (coef0 + 2 < n_mfcc) orow[2] = d.y;
@@ -1202,7 +1232,7 @@ void stft_wave1024_kernel(
         }
         src_chunk += src_stride;
         out_chunk += out_stride;
-        frames_left -= frames_per_wg;
+        frames_left -= frames_step;
     }
     AA_CLK_END
 }
@@ -1411,10 +1441,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                     const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
                     const v2f x0 = scr[1];                         // complex 0 of an odd row
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_nontemporal_store(q0, gw4);
-                    __builtin_nontemporal_store(q1, gw4 + 64);
-                    __builtin_nontemporal_store(q2, gw4 + 128);
-                    __builtin_nontemporal_store(q3, gw4 + 192);
+                    row_store(q0, gw4);
+                    row_store(q1, gw4 + 64);
+                    row_store(q2, gw4 + 128);
+                    row_store(q3, gw4 + 192);
                     if (lane == 0 && shc)
                         reinterpret_cast<v2f *>(row)[0] = x0;
                 }
@@ -1429,10 +1459,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                     const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
                     const v2f x1024 = scr[512];                    // complex 1024 of an even row
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_nontemporal_store(q0, gw4 + 256);
-                    __builtin_nontemporal_store(q1, gw4 + 320);
-                    __builtin_nontemporal_store(q2, gw4 + 384);
-                    __builtin_nontemporal_store(q3, gw4 + 448);
+                    row_store(q0, gw4 + 256);
+                    row_store(q1, gw4 + 320);
+                    row_store(q2, gw4 + 384);
+                    row_store(q3, gw4 + 448);
                     if (lane == 0 && !shc)
                         reinterpret_cast<v2f *>(row)[1024] = x1024;
                 }
@@ -1485,7 +1515,7 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                         const int ls = (pce == 3 && lane == 63) ? 62 : lane;   // keep the last read in range
                         v4f bb = *reinterpret_cast<const v4f *>(lw + 4 + 256 * pce + 4 * ls);
                         if (pce < 3 || lane < 63)
-                            __builtin_nontemporal_store(bb, reinterpret_cast<v4f *>(gw + 4 + 256 * pce + 4 * lane));
+                            row_store(bb, reinterpret_cast<v4f *>(gw + 4 + 256 * pce + 4 * lane));
                     }
                     const int hi = lane < 4 ? lane : 1020 + lane;
                     const float hv = lw[lane < 8 ? hi : 0];
@@ -1790,20 +1820,20 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
                     v4f b0 = *reinterpret_cast<const v4f *>(scrf + 4 * lane);
                     v4f b1 = *reinterpret_cast<const v4f *>(scrf + 256 + 4 * lane);
                     v4f b2 = *reinterpret_cast<const v4f *>(scrf + 512 + 4 * (lane & 1));
-                    __builtin_nontemporal_store(b0, reinterpret_cast<v4f *>(grp + 4 * lane));
-                    __builtin_nontemporal_store(b1, reinterpret_cast<v4f *>(grp + 256 + 4 * lane));
+                    row_store(b0, reinterpret_cast<v4f *>(grp + 4 * lane));
+                    row_store(b1, reinterpret_cast<v4f *>(grp + 256 + 4 * lane));
                     if (4 * lane < G::ROW_FLOATS - 512)
-                        __builtin_nontemporal_store(b2, reinterpret_cast<v4f *>(grp + 512 + 4 * lane));
+                        row_store(b2, reinterpret_cast<v4f *>(grp + 512 + 4 * lane));
                 } else if (WIDE && nvalid == FPW) {
                     // 514 floats = 257 float2, group start 8-byte aligned
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         v2f b = *reinterpret_cast<const v2f *>(scrf + 128 * u + 2 * lane);
-                        __builtin_nontemporal_store(b, reinterpret_cast<v2f *>(grp + 128 * u + 2 * lane));
+                        row_store(b, reinterpret_cast<v2f *>(grp + 128 * u + 2 * lane));
                     }
                     v2f bt = *reinterpret_cast<const v2f *>(scrf + 512);
                     if (lane == 0)
-                        __builtin_nontemporal_store(bt, reinterpret_cast<v2f *>(grp + 512));
+                        row_store(bt, reinterpret_cast<v2f *>(grp + 512));
                 } else {
                     const int nfl = NB * nvalid;
 #pragma unroll
@@ -2283,9 +2313,15 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
         cached_grid = persistent_grid(stft_wave1024_kernel<K, 0, true>, lds);
         cached_lds = lds;
     }
-    const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
+    int64_t want = cached_grid;
+    if (const char *e = getenv("AA_GRID_SET"))           // experiments: another number of persistent workgroups
+        want = atoi(e) > 0 ? atoi(e) : want;
+    const dim3 grid((unsigned)(want < chunks ? want : chunks)), block(kWave1024Threads);
+#ifndef AA_V_ABL
+#define AA_V_ABL 0      // experiments: an ablation / variant mask of stft_wave1024_kernel in the product launcher
+#endif
     if (wide)
-        hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, true>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc);
     else
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
