@@ -942,3 +942,20 @@ def test_every_row_of_a_many_chunk_launch(aa, oracle_mod, torch_mod, n, hop, out
     tol = TOL_VS_TRUTH if output in ("mag", "complex") else 2e-5
     e = nerr(got, ref)
     assert e.max() <= tol, (int(np.argmax(e)), float(e.max()))
+
+
+@pytest.mark.parametrize("hop", [64, 128, 512, 1024])
+def test_fused_mfcc_other_hops(aa, oracle_mod, torch_mod, hop):
+    """The fused MFCC kernel at hops other than n_fft / 4 (the block bookkeeping is per chunk, not per hop)."""
+    sr, n, n_mels, n_mfcc = 48000, 1024, 128, 40
+    tr = oracle_mod.truth
+    dct, fb = tr.dct2_ortho(n_mfcc, n_mels), tr.mel_filterbank(sr, n, n_mels)
+    plan = aa.Stft(n, hop, output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc)
+    rng = np.random.default_rng(hop)
+    for nf in (1, 9, 16, 23, 777):
+        L = n + (nf - 1) * hop
+        x = (aa.signals.synth_corpus(3, L) + 1e-3 * rng.standard_normal(L)).astype(np.float32)
+        got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+        P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+        ref = (10.0 * np.log10(np.maximum(P @ fb.T, 1e-10))) @ dct.T
+        assert got.shape == ref.shape and nerr(got, ref).max() < 1e-5
