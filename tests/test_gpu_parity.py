@@ -959,3 +959,59 @@ def test_fused_mfcc_other_hops(aa, oracle_mod, torch_mod, hop):
         P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
         ref = (10.0 * np.log10(np.maximum(P @ fb.T, 1e-10))) @ dct.T
         assert got.shape == ref.shape and nerr(got, ref).max() < 1e-5
+
+
+# ------------------------- the whole widened path, raw samples in, decisions out, vs the oracle chain --
+def test_conditioned_session_end_to_end_vs_oracle_chain(aa, oracle_mod, torch_mod):
+    """Rows f-3 -> a -> f-1 / f-2 in one piece, product against the CPU restatement stage by stage: raw
+    samples -> conditioner (host C++, aa_conditioner_*; mod.rs:351-478, dynamics.rs:152-360) -> the
+    two STFT geometries on the GPU -> onset flux / gates and tuner floor / pitches driven by the
+    conditioner's noise floor (global_floor per frame, stft.rs:322-324, onset.rs:299-300).  The
+    restatement chain (oracle.condition -> oracle.stft -> oracle.onset_* / tuner_*) runs on its own
+    conditioned samples and its own CPU spectra: the conditioner must agree bit for bit, the spectra
+    to the STFT tolerance, and the decisions (onset flags, note counts) in all but a handful of frames
+    (they sit behind thresholds; a 1e-7 difference in a magnitude may move one across)."""
+    from conftest import TOL_VS_ORACLE
+    from test_oracle import _burst_signal, _chord_signal
+
+    rng = np.random.default_rng(5)
+    raw = np.concatenate([_burst_signal(seconds=6.0, seed=3), 0.5 * _chord_signal(seconds=5.0, seed=4),
+                          (3e-4 * rng.standard_normal(48000 * 3)).astype(np.float32)]).astype(np.float32)
+    # f-3: product (host C++) vs restatement, bit for bit
+    y, dyn = aa.Conditioner().process(raw)
+    ry, rdyn = oracle_mod.condition(raw)
+    assert np.array_equal(y, ry)
+    for k in rdyn:
+        assert np.array_equal(dyn[k], rdyn[k]), k
+    yd = torch_mod.from_numpy(y).cuda()
+    # onset chain, 256 / 64
+    om = aa.Stft(256, 64, output="mag")(yd)
+    rom = oracle_mod.stft(ry, 256, 64, kind="mag")
+    assert nerr(om.cpu().numpy(), rom.astype(np.float64)).max() <= TOL_VS_ORACLE
+    gf_o = aa.global_floor_per_frame(dyn["noise_floor_db"], om.shape[0], 256, 64, 129)
+    flux, energy = aa.onset_flux(om)
+    gates, _ = aa.onset_gates(om, flux, energy, torch_mod.from_numpy(gf_o).cuda())
+    rflux, renergy = oracle_mod.onset_flux(rom)
+    rgates, _, _ = oracle_mod.onset_gates(rom, rflux, renergy, gf_o)
+    assert np.allclose(flux.cpu().numpy(), rflux, rtol=2e-4, atol=1e-6)
+    fired = (gates["flags"].cpu().numpy() & aa.stft.ONSET_FLAG_FIRED) != 0
+    rfired = (rgates["flags"] & aa.stft.ONSET_FLAG_FIRED) != 0
+    assert rfired.sum() >= 15 and np.sum(fired != rfired) <= 2
+    # tuner chain, 2048 / 512
+    tm = aa.Stft(2048, 512, output="mag")(yd)
+    rtm = oracle_mod.stft(ry, 2048, 512, kind="mag")
+    assert nerr(tm.cpu().numpy(), rtm.astype(np.float64)).max() <= TOL_VS_ORACLE
+    gf_t = aa.global_floor_per_frame(dyn["noise_floor_db"], tm.shape[0], 2048, 512, 1025)
+    eff, _ = aa.tuner_floor(tm, torch_mod.from_numpy(gf_t).cuda())
+    reff, _, _ = oracle_mod.tuner_floor(rtm, gf_t)
+    # (per-bin recurrence on magnitudes: leakage bins differ by their own size between two correct f32 FFTs,
+    # so the criterion is the path's max-normalised one; the floor also sits behind per-bin decisions - a bin
+    # whose magnitude crosses its floor in one chain and not in the other follows another branch for a while)
+    fe = nerr(eff.cpu().numpy(), reff.astype(np.float64))
+    assert np.median(fe) <= 1e-5 and np.mean(fe <= 1e-3) > 0.98, (float(np.median(fe)), float(fe.max()), float(np.mean(fe <= 1e-3)))
+    freq, score, count = aa.tuner_pitches(tm, eff, 48000 / 2048)
+    rf, rs, rc = oracle_mod.extract_pitches(rtm, reff, 48000 / 2048)
+    count = count.cpu().numpy()
+    same = count == rc
+    assert same.mean() > 0.98 and rc.max() >= 3
+    assert np.allclose(freq.cpu().numpy()[same], rf[same], rtol=1e-4, atol=0.0)
