@@ -116,6 +116,28 @@ int nccl_fail(const char *what, ncclResult_t r)
             return nccl_fail(#expr, r_);                                                       \
     } while (0)
 
+// ncclGroupStart .. ncclGroupEnd with the end guaranteed: an error between the two must not leave
+// the group open (every later RCCL call of the thread would queue into it).
+struct GroupScope {
+    bool open = false;
+    ncclResult_t begin()
+    {
+        ncclResult_t r = g_rccl.GroupStart();
+        open = r == 0;
+        return r;
+    }
+    ncclResult_t end()
+    {
+        open = false;
+        return g_rccl.GroupEnd();
+    }
+    ~GroupScope()
+    {
+        if (open)
+            (void)g_rccl.GroupEnd();
+    }
+};
+
 void frames_of(int64_t total, int world, int r, int64_t *f0, int64_t *f1)
 {
     *f0 = (int64_t)(((__int128)total * r) / world);          // == aa_shard_frames
@@ -212,12 +234,13 @@ int aa_comm_barrier(aa_comm *c, void *stream)
     if (!c)
         return fail(AA_ERR_ARG, "aa_comm_barrier: NULL comm");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    NCCL_TRY(g_rccl.GroupStart());
+    GroupScope grp;
+    NCCL_TRY(grp.begin());
     for (int r = 0; r < c->world; ++r) {
         NCCL_TRY(g_rccl.Send(c->token + r, 1, kNcclFloat32, r, c->comm, st));
         NCCL_TRY(g_rccl.Recv(c->token + c->world + r, 1, kNcclFloat32, r, c->comm, st));
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY(grp.end());
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess)
         return fail(AA_ERR_HIP, "aa_comm_barrier: %s", hipGetErrorString(e));
@@ -246,7 +269,8 @@ int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int
             if (e != hipSuccess)
                 return fail(AA_ERR_HIP, "aa_scatter_samples: %s", hipGetErrorString(e));
         }
-        NCCL_TRY(g_rccl.GroupStart());
+        GroupScope grp;
+        NCCL_TRY(grp.begin());
         for (int r = 0; r < c->world; ++r) {
             if (r == root)
                 continue;
@@ -256,7 +280,7 @@ int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int
             if (t1 > t0)
                 NCCL_TRY(g_rccl.Send(full_dev + t0, (size_t)(t1 - t0), kNcclFloat32, r, c->comm, st));
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        NCCL_TRY(grp.end());
     } else if (s1 > s0) {
         NCCL_TRY(g_rccl.Recv(local_dev, (size_t)(s1 - s0), kNcclFloat32, root, c->comm, st));
     }
@@ -282,7 +306,8 @@ int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int3
     }
     if (c->world == 1)
         return AA_OK;
-    NCCL_TRY(g_rccl.GroupStart());
+    GroupScope grp;
+    NCCL_TRY(grp.begin());
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank)
             continue;
@@ -295,7 +320,7 @@ int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int3
                 NCCL_TRY(g_rccl.Recv(out_dev + g0 * cols, (size_t)((g1 - g0) * cols), kNcclFloat32, r, c->comm, st));
         }
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY(grp.end());
     return AA_OK;
 }
 

@@ -642,6 +642,9 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_TAIL
 #define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
 #endif
+#ifndef AA_V_DMA_AUX
+#define AA_V_DMA_AUX 0     // cache policy bits of the LDS-DMA sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef AA_V_ILV
 #define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
 #endif
@@ -770,7 +773,7 @@ void stft_wave1024_kernel(
             if (q < span4)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(src + 4 * q),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
         }
     };
 
@@ -1324,7 +1327,7 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             if (q < span4)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(src + 4 * q),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
         }
     };
     if (c0 < c1)
@@ -1624,7 +1627,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             if (qq < span4)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(src + 4 * qq),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, 0);
+                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
         }
     };
     if (c0 < c1)
