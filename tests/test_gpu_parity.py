@@ -3,6 +3,8 @@
 the checker.  Tolerances: per frame max_k|out-ref| / max_k|ref| <= 1e-5 against the CPU
 restatement (BASELINE.json north_star), <= 5e-6 against the float64 truth; frame
 indexing exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1015,3 +1017,19 @@ def test_conditioned_session_end_to_end_vs_oracle_chain(aa, oracle_mod, torch_mo
     same = count == rc
     assert same.mean() > 0.98 and rc.max() >= 3
     assert np.allclose(freq.cpu().numpy()[same], rf[same], rtol=1e-4, atol=0.0)
+
+
+def test_logmel_and_mfcc_against_committed_golden(aa, torch_mod):
+    """configs[2] / configs[4] against the committed vectors (tests/golden/mel_golden.npz, float64):
+    log-mel at 2048 / 512 and 1024 / 256 (linear-domain max-normalised <= 2e-5), MFCC at 1024 / 256
+    (fused kernel) and 2048 / 512 (two-launch path) <= 1e-5."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mel_golden.npz")
+    with np.load(path, allow_pickle=False) as z:
+        for key in sorted(k[:-2] for k in z.files if k.endswith("_x")):
+            n = int(key[1:].split("_")[0])
+            x, mel, mfcc = z[key + "_x"], z[key + "_mel"], z[key + "_mfcc"]
+            xd = torch_mod.from_numpy(x).cuda()
+            lm = aa.Stft(n, n // 4, output="logmel", sample_rate=48000, n_mels=128)(xd).cpu().numpy()
+            assert nerr(10.0 ** (lm.astype(np.float64) / 10.0), np.maximum(mel, 1e-10)).max() < 2e-5, key
+            mf = aa.Stft(n, n // 4, output="mfcc", sample_rate=48000, n_mels=128, n_mfcc=40)(xd).cpu().numpy()
+            assert nerr(mf, mfcc).max() < 1e-5, key

@@ -1,9 +1,13 @@
 """CPU tests: the C restatement (oracle/) against the float64 truth, the committed golden
 vectors, and the integer framing / ring-buffer rules of the reference."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import GOLDEN_GEOMETRIES, GOLDEN_SIGNALS, TOL_VS_TRUTH
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_hann_matches_reference_formula(oracle_mod, golden):
@@ -362,3 +366,23 @@ def test_detector_restatements_vs_golden(oracle_mod):
     assert np.allclose(freq, g["tuner_freq"], rtol=1e-6) and np.allclose(score, g["tuner_score"], rtol=1e-6)
     sf, ss, sc = oracle_mod.pitch_tracker(g["tuner_freq"], g["tuner_score"], g["tuner_count"])
     assert np.array_equal(sc, g["tracker_count"]) and np.array_equal(sf[:, :8], g["tracker_freq"])
+
+
+def test_mel_definition_matches_committed_golden(oracle_mod):
+    """The float64 log-mel / MFCC definition (oracle/truth.py; build-defined, parity unpinned by the
+    reference) reproduces tests/golden/mel_golden.npz: a change of the mel scale, the normalisation,
+    the log floor or the DCT convention shows up here before it shows up on the GPU."""
+    path = os.path.join(ROOT, "tests", "golden", "mel_golden.npz")
+    tr = oracle_mod.truth
+    dct = tr.dct2_ortho(40, 128)
+    with np.load(path, allow_pickle=False) as z:
+        keys = sorted(k[:-2] for k in z.files if k.endswith("_x"))
+        assert len(keys) == 6
+        for key in keys:
+            n = int(key[1:].split("_")[0])
+            x, mel, mfcc = z[key + "_x"], z[key + "_mel"], z[key + "_mfcc"]
+            P = np.abs(tr.stft_complex(x, n, n // 4, oracle_mod.hann_window(n))) ** 2
+            got = P @ tr.mel_filterbank(48000, n, 128).T
+            assert got.shape == mel.shape == (20, 128) and np.allclose(got, mel, rtol=1e-12, atol=0.0)
+            got_mfcc = (10.0 * np.log10(np.maximum(got, 1e-10))) @ dct.T
+            assert np.allclose(got_mfcc, mfcc, rtol=1e-10, atol=1e-10)
