@@ -169,3 +169,17 @@ def test_comm_argument_errors_without_a_gpu(lib):
     assert lib.aa_gather_rows(None, None, 10, 513, 0, None, None) == _lib.AA_ERR_ARG
     assert lib.aa_scatter_samples(None, None, 10, 1024, 256, 0, None, 0, None) == _lib.AA_ERR_ARG
     assert isinstance(lib.aa_comm_backend(), bytes)
+
+
+def test_stream_create_rejects_bad_hops_before_touching_a_device(lib):
+    """aa_stream_create: hop == 0 would emit one frame for ever, hop > n_fft would drive the ring's
+    `available` count negative (a usize underflow in the reference, stft.rs:436-437) - both are
+    AA_ERR_ARG, checked before any plan (and so any device) is involved."""
+    from audio_analyzer_rs_amd import _lib
+
+    for n_fft, hop in ((1024, 0), (1024, -5), (1024, 1025), (0, 0)):
+        cfg = _lib.StftConfig(n_fft, hop, _lib.AA_WINDOW_HANN_PERIODIC, _lib.AA_OUT_MAG, 48000, 0, 0, 0.0, 0.0, 0.0)
+        h = ctypes.c_void_p()
+        assert lib.aa_stream_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == _lib.AA_ERR_ARG
+        assert not h.value
+        assert b"hop" in lib.aa_last_error()
