@@ -1033,3 +1033,27 @@ def test_logmel_and_mfcc_against_committed_golden(aa, torch_mod):
             assert nerr(10.0 ** (lm.astype(np.float64) / 10.0), np.maximum(mel, 1e-10)).max() < 2e-5, key
             mf = aa.Stft(n, n // 4, output="mfcc", sample_rate=48000, n_mels=128, n_mfcc=40)(xd).cpu().numpy()
             assert nerr(mf, mfcc).max() < 1e-5, key
+
+
+def test_execute_device_rejects_unusable_out_buffers(aa, torch_mod):
+    """The wave kernels write nf * cols floats with 16-byte nontemporal stores: a short, strided, wrongly
+    typed or host-side `out` must be refused (AaError), not become an out-of-bounds device write
+    (ADVICE, round 1); the host path refuses arguments it would otherwise drop silently."""
+    plan = aa.Stft(1024, 256, output="mag")
+    x = aa.signals.synth_corpus(0, 1024 + 99 * 256)
+    xd = torch_mod.from_numpy(x).cuda()
+    good = torch_mod.empty((100, 513), device="cuda")
+    assert plan.execute_device(xd, 0, 100, out=good).data_ptr() == good.data_ptr()
+    bad = [torch_mod.empty((99, 513), device="cuda"),                       # short
+           torch_mod.empty((100, 513), device="cuda", dtype=torch_mod.float64),
+           torch_mod.empty((100, 1026), device="cuda")[:, ::2],             # strided
+           torch_mod.empty((100, 513))]                                     # host memory
+    for out in bad:
+        with pytest.raises(aa.AaError):
+            plan.execute_device(xd, 0, 100, out=out)
+    with pytest.raises(aa.AaError):
+        plan.execute_device(xd, 5, 101)                                      # range past the last frame
+    with pytest.raises(aa.AaError):
+        plan(x, frame_begin=3)                                               # host path: whole buffer only
+    host_out = np.empty((100, 513), np.float32)
+    assert plan(x, out=host_out) is host_out
