@@ -90,3 +90,37 @@ def test_bench_refuses_mismatched_world(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_bench_helpers_on_cpu(monkeypatch):
+    """bench.py pieces that need no GPU: the row picker covers both ends and the ragged tail, the
+    checker flags a wrong row, and `--gpus N` without WORLD_SIZE re-launches itself under
+    torch.distributed.run on 127.0.0.1 with the same arguments (nothing touches the GPU before that)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import audio_analyzer_rs_amd as aa
+
+    ids = bench.pick_rows(112497, 96)
+    assert len(ids) == 96 and set(range(16)) <= set(ids) and set(range(112497 - 16, 112497)) <= set(ids)
+    assert list(bench.pick_rows(5, 64)) == [0, 1, 2, 3, 4]
+    x = aa.signals.synth_corpus(0, 1024 + 9 * 256)
+    import oracle
+
+    rows = oracle.stft(x, 1024, 256, kind="mag")
+    assert bench.check_rows(x, rows, np.arange(10), 1024, 256, "mag") < bench.TOL_VS_TRUTH
+    bad = rows.copy()
+    bad[3] = rows[4]
+    assert bench.check_rows(x, bad, np.arange(10), 1024, 256, "mag") > 1e-2
+    cx = oracle.stft(x, 1024, 256, kind="complex")
+    assert bench.check_rows(x, cx, np.arange(10), 1024, 256, "complex") < bench.TOL_VS_TRUTH
+    calls = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "--master-addr" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
