@@ -143,11 +143,11 @@ def cpu_baseline(x, min_seconds=8.0, max_reps=20):
         pass
     return {
         "value": r4(single), "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"10-min buffer ({nf} frames) x {reps} passes, {dt:.1f} s, 1 thread; scalar radix-2 C "
-                  "port (gcc -O3 -mavx2 -ffp-contract=off), not the Rust/rustfft binary",
+        "sample": f"10-min buffer x {reps} passes, {dt:.1f} s, 1 thread; scalar radix-2 C port "
+                  "(gcc -O3 -mavx2 -ffp-contract=off), not the rustfft binary",
         "all_cores": {"value": r4(multi), "cores": cores},
         "config0": {"value": r4(r0 * nf0 / d0), "unit": "frames/s", "cores": 1,
-                    "sample": f"60 s PCM16 mono 48 kHz stand-in ({nf0} frames) x {r0} passes, {d0:.1f} s"},
+                    "sample": f"60 s PCM16 stand-in ({nf0} frames) x {r0} passes, {d0:.1f} s"},
         "cpu_model": cpu_model,
     }
 
@@ -359,8 +359,8 @@ def run_single(args):
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: batched 1024-pt STFT, hop 256, periodic Hann, |X| out, 10 min "
-                        f"synthetic 48 kHz mono f32 ({nf} frames)",
+            "workload": f"configs[1]: batched 1024-pt STFT, hop 256, Hann, |X|, 10 min synthetic 48 kHz mono "
+                        f"f32 ({nf} frames)",
             "n_fft": N_FFT, "hop": HOP, "output": "mag", "frames_total": nf, "kernel": plan.kernel,
         },
         "roofline": {
@@ -369,7 +369,7 @@ def run_single(args):
             "traffic": traffic, "traffic_from_profile": traffic_src,
             "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": nf,
         },
-        "post_check_max_err": post_err, "post_check_rows": int(len(ids)), "post_check_tol": TOL_VS_TRUTH,
+        "post_check_max_err": r4(post_err), "post_check_rows": int(len(ids)), "post_check_tol": TOL_VS_TRUTH,
     }
     ok = post_err <= TOL_VS_TRUTH
     detail = dict(result)
