@@ -681,6 +681,22 @@ __device__ __forceinline__ void rotate_wave_priority(int step)
     }
 }
 
+// The fused log-mel variant of the 2048 kernel keeps THREE workgroups per CU and has a third long phase
+// (the mel gather): it rotates over three priority levels at three points per frame - chunk top, after the
+// first exchange, in front of the gather: 113.5 -> 107.5 us per channel (A/B, alternating processes).  The
+// magnitude variants lose 1.7 % with three levels and keep the four-level pattern; the 1024 mel kernels
+// lose 5 % with a fifth rotation point and 5-7 % with three levels.
+__device__ __forceinline__ void rotate_wave_priority3(int step)
+{
+    if (!AA_PRIO_ROTATE)
+        return;
+    switch (step % 3) {
+    case 0: __builtin_amdgcn_s_setprio(2); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
+
 // ---------------------------------------------------- wave-per-frame, n_fft = 1024 --
 // One wavefront transforms one frame: the 1024 windowed reals are read as 512 complex points
 // z[m] (8 per lane), 512 = 8 x 8 x 8:
@@ -1367,8 +1383,11 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        const int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority
-        rotate_wave_priority(prio_step);
+        const int prio_step = (int)(blockIdx.x >> 8) + (MEL ? 3 : 2) * (c - c0);   // see rotate_wave_priority[3]
+        if (MEL)
+            rotate_wave_priority3(prio_step);
+        else
+            rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
@@ -1390,7 +1409,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             fft512_exchange1(e, e1_wr, e1_rd);
             fft512_pass_a(o, twA);
             fft512_exchange1(o, e1_wr, e1_rd);
-            rotate_wave_priority(prio_step + 1);
+            if (MEL)
+                rotate_wave_priority3(prio_step + 1);
+            else
+                rotate_wave_priority(prio_step + 1);
             fft512_pass_bc(e, twB);
             fft512_pass_bc(o, twB);
             // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
@@ -1496,6 +1518,7 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                     if (lane == 0)
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
+                    rotate_wave_priority3(prio_step + 2);
                     mel_reduce<1>(lrow, NB, melpar, sch, melstage);
                     mel_store<1>(melstage, sch, log_floor, row, nullptr, false);
                 } else if (WIDE) {
