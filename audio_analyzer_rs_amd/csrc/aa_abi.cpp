@@ -335,6 +335,67 @@ bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, int ma
     return true;
 }
 
+// kLogMelR of the 2048 kernel (aa_internal.hpp: kMelStreamTableDwords): the schedule of
+// build_mel_resident with up to kMelStreamMaxSteps steps, the weights laid out for one
+// global_load_dwordx4 per (step, lane) and the byte offsets packed two per dword.
+bool build_mel_streamed(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab,
+                        aa::MelSched *sch)
+{
+    if (n_mels < 1 || n_mels > aa::kMelMaxMels || 4 * nb > 65535)
+        return false;
+    std::vector<int> lo(n_mels, 0), len(n_mels, 0);
+    for (int m = 0; m < n_mels; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (w[(size_t)m * nb + k] != 0.0) {
+                if (first < 0)
+                    first = k;
+                last = k;
+            }
+        if (first >= 0) {
+            lo[m] = first;
+            len[m] = last - first + 1;
+        }
+    }
+    // a group's end costs one or two steps' worth of instructions (K-slice sums, the store)
+    int best_steps = 0;
+    for (int overhead : {4, 2}) {
+        aa::MelSched cand;
+        if (!plan_mel_groups(len, n_mels, 64, nb, overhead, &cand))
+            continue;
+        int steps = 0;
+        for (int g = 0; g < cand.n_groups; ++g)
+            steps += cand.trips[g] / 4;
+        if (steps >= 1 && (best_steps == 0 || steps < best_steps)) {
+            best_steps = steps;
+            *sch = cand;
+        }
+    }
+    if (best_steps < 1 || best_steps > aa::kMelStreamMaxSteps)
+        return false;
+    sch->n_steps = best_steps;
+    tab->assign(aa::kMelStreamTableDwords, 0.0f);
+    uint32_t *offs = reinterpret_cast<uint32_t *>(tab->data() + (size_t)aa::kMelStreamMaxSteps * 64 * 4);
+    int s = 0;
+    for (int g = 0; g < sch->n_groups; ++g) {
+        const int pl = sch->part_log2[g], parts = 1 << pl, trips = sch->trips[g], base = sch->mel_base[g];
+        for (int t = 0; t < trips / 4; ++t, ++s) {
+            sch->step_info[s] = (t == trips / 4 - 1 ? 1 : 0) | (pl << 1) | (base << 4);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int msub = lane & ((64 >> pl) - 1), h = lane >> (6 - pl), mel = base + msub;
+                if (mel >= n_mels)
+                    continue;   // weights 0, offset 0
+                const int ks = std::max(0, std::min(lo[mel], nb - parts * trips));
+                const int k0 = ks + h * trips + 4 * t;
+                for (int j = 0; j < 4; ++j)
+                    (*tab)[((size_t)s * 64 + lane) * 4 + j] = k0 + j < nb ? (float)w[(size_t)mel * nb + k0 + j] : 0.0f;
+                offs[lane * 8 + (s >> 1)] |= (4u * (uint32_t)k0) << (16 * (s & 1));
+            }
+        }
+    }
+    return true;
+}
+
 // Per-lane constants of the wave-per-frame 2048 kernel, [kWave2048Rows][64] (row meaning in
 // aa_kernels.hip above stft_wave2048_kernel).
 void build_wave2048_table(const float *window, std::vector<float> *tab)
@@ -522,10 +583,10 @@ struct aa_stft_plan {
     int64_t ws_logmel_rows = 0;
     // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
     bool fused_mel = false;
-    bool mel_resident = false;     // 1024 kernel with the filter weights resident in registers (kLogMelR)
+    bool mel_resident = false;     // kLogMelR: filter weights from a per-lane table (1024: resident in registers; 2048: streamed)
     bool mfcc_fused = false;       // ... and the DCT-II behind it on the matrix cores (kMfccR)
     float *d_dct_lane = nullptr;   // its per-lane A-operand table [tile][8][64] float4
-    float *d_mel_par = nullptr;    // [kMelParTableDwords] or [kMelResidentTableDwords]
+    float *d_mel_par = nullptr;    // [kMelParTableDwords], [kMelResidentTableDwords] or [kMelStreamTableDwords]
     aa::MelSched mel_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
     hipStream_t pipe_stream[2] = {nullptr, nullptr};
@@ -903,11 +964,12 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                              : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384;
             const char *no_res = std::getenv("AA_MEL_NO_RESIDENT");
             bool ok = false;
-            if (mel_lds_ok && !(no_res && std::atoi(no_res) != 0) && p->wave1024) {
+            if (mel_lds_ok && !(no_res && std::atoi(no_res) != 0)) {
                 std::vector<double> w;
                 mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
                 ok = p->mel_resident =
-                    build_mel_resident(w, nb, cfg->n_mels, aa::kMelResidentSteps1024, &par, &p->mel_sched);
+                    p->wave1024 ? build_mel_resident(w, nb, cfg->n_mels, aa::kMelResidentSteps1024, &par, &p->mel_sched)
+                                : build_mel_streamed(w, nb, cfg->n_mels, &par, &p->mel_sched);
             }
             if (!ok && mel_lds_ok)
                 ok = build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes, &par,
@@ -925,7 +987,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             // [tile][S][lane][t] = d[c][16 S + 4 kq + t], orthonormal DCT-II as above; zero outside
             // n_mfcc / n_mels / 2.
             const char *no_fuse = std::getenv("AA_MFCC_NO_FUSE");
-            if (ok && p->mel_resident && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
+            if (ok && p->mel_resident && p->wave1024 && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
                 cfg->n_mels <= aa::kMelMaxMels && cfg->n_mels % 2 == 0 && !(no_fuse && std::atoi(no_fuse) != 0) &&
                 aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384) {
                 std::vector<float> dl((size_t)aa::kMfccTableDwords, 0.0f);
@@ -1057,7 +1119,8 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
     if (p->fused_mel && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
         auto mel_stage = [&](int64_t fb, int64_t n, float *dst) -> int {
             if (p->wave2048)
-                AA_HIP(aa::launch_wave2048(aa::kLogMel, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                AA_HIP(aa::launch_wave2048(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
+                                           p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
             else
                 AA_HIP(aa::launch_wave1024(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,

@@ -52,13 +52,22 @@ struct MelSched {
     // kLogMelR only: the groups flattened into n_steps 4-bin steps;
     // step_info[s] = last step of its group (bit 0) | part_log2 << 1 | mel_base << 4
     int n_steps = 0;
-    int step_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int step_info[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 // kLogMelR (1024 kernel, weights resident in registers): the schedule must fit
 // kMelResidentSteps1024 steps of 4 bins (36 VGPRs); per-lane table [steps][5][64]: 4 weights + the
 // byte offset of the step's first bin in the power row (< 65536; the kernel packs two per register).
 constexpr int kMelResidentSteps1024 = 8;
 constexpr int kMelResidentTableDwords = kMelResidentSteps1024 * 5 * 64;
+// kLogMelR in the 2048 kernel: the same flattened schedule with the weights STREAMED from a per-lane
+// table every frame (the 2048 kernel has no registers to keep them: 168 of 170 at three waves per
+// SIMD) - one global_load_dwordx4 per 4-bin step replaces the nine VALU instructions that rebuild
+// the weights from the triangle edges (mel_reduce).  The table (<= 18 KB, read by every wave of the
+// chip once per frame) lives in the L1 / L2.  Layout: [kMelStreamMaxSteps][64 lanes][4] weights, then
+// [64 lanes][8] dwords of byte offsets into the power row, two 16-bit values per dword (step 2 i in
+// the low half of dword i).  The kernel is instantiated for 12, 14 and 16 steps.
+constexpr int kMelStreamMaxSteps = 16;
+constexpr int kMelStreamTableDwords = kMelStreamMaxSteps * 64 * 4 + 64 * 8;
 
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see
@@ -97,6 +106,7 @@ inline size_t wave2048_lds_bytes(int frames_per_wg, int hop, bool mel = false)
 {
     return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop, mel);
 }
+// kLogMelR: mel_par is the streamed table (kMelStreamTableDwords), sched->n_steps <= kMelStreamMaxSteps.
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,

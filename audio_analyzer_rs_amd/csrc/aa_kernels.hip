@@ -599,6 +599,112 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
         }
     }
 }
+// kLogMelR in the 2048 kernel (F = 1): the schedule of mel_reduce_resident with the weights STREAMED
+// from the per-lane table (aa_internal.hpp: kMelStreamTableDwords) - the kernel has no registers to
+// keep them, and rebuilding them from the triangle edges (mel_reduce) costs nine VALU instructions
+// per 4-bin step against one global_load_dwordx4 here.  A step: the lane's four weights (global,
+// DW steps ahead), its four bins (two hand-issued ds_read2_b32, DL steps ahead), one v_pk_mul +
+// v_pk_fma + add.  The table is read once per frame by every wave of the chip and stays in the
+// L1 / L2.  All NS steps run (steps past the schedule have zero weights and read bins 0..3).
+template <int NS>
+__device__ __forceinline__ void mel_reduce_streamed(unsigned rows_addr, const float *tab, const MelSched &sch,
+                                                    float *stage)
+{
+    static_assert(NS <= kMelStreamMaxSteps && NS % 2 == 0, "streamed mel schedule");
+#ifndef AA_MEL_DL
+#define AA_MEL_DL 4
+#endif
+#ifndef AA_MEL_DW
+#define AA_MEL_DW 3
+#endif
+    constexpr int DL = AA_MEL_DL;                    // LDS steps in flight (two loads each; lgkmcnt counts to 15)
+    constexpr int DW = AA_MEL_DW;                    // weight loads in flight
+    const int ln = threadIdx.x & 63;
+    // the lane's byte offset into a table row: one 32-bit register next to the uniform base (saddr
+    // addressing).  Opaque, so that the per-step addresses are not hoisted out of the frame loop.
+    unsigned voff = 16u * (unsigned)ln;
+    asm volatile("" : "+v"(voff), "+v"(rows_addr));
+    // (opaque base as well: else every step's row address becomes a hoisted SGPR pair)
+    const char *tabb = reinterpret_cast<const char *>(tab);
+    unsigned sbase = 0;
+    asm volatile("" : "+s"(sbase));
+    auto weights = [&](int s) { return *reinterpret_cast<const v4f *>(tabb + (sbase + 1024u * s) + voff); };
+    const uint4 oa = *reinterpret_cast<const uint4 *>(tabb + 1024 * kMelStreamMaxSteps + 2 * voff);
+    const uint4 ob = NS > 8 ? *reinterpret_cast<const uint4 *>(tabb + 1024 * kMelStreamMaxSteps + 16 + 2 * voff)
+                            : uint4{0u, 0u, 0u, 0u};
+    const unsigned off2[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+    v4f W[NS];
+#pragma unroll
+    for (int s = 0; s < DW && s < NS; ++s)
+        W[s] = weights(s);
+    v2f P[NS][2];
+    auto issue = [&](int s) {
+        const unsigned aa = rows_addr + ((s & 1) ? off2[s >> 1] >> 16 : off2[s >> 1] & 0xffffu);
+        P[s][0] = mel_lds_load2<0>(aa);
+        P[s][1] = mel_lds_load2<2>(aa);
+    };
+#pragma unroll
+    for (int s = 0; s < DL && s < NS; ++s)
+        issue(s);
+    float ra[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        v2f(&c)[2] = P[s];
+        constexpr int kMax = (DL - 1) * 2;
+        const int newer = (NS - 1 - s) * 2;          // LDS loads issued after this step's
+        if (newer >= kMax)
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(kMax) : "memory");
+        else if (newer == 10)
+            asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        else if (newer == 8)
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        else if (newer == 6)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        else if (newer == 4)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        else if (newer == 2)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1])::"memory");
+        const v2f w01 = {W[s].x, W[s].y}, w23 = {W[s].z, W[s].w};
+        const v2f r2 = w23 * c[1] + w01 * c[0];
+        ra[s] = r2.x + r2.y;
+        // the step ends here: its registers die, the loads of the steps DL / DW ahead reuse them
+        asm volatile("" : "+v"(ra[s]), "+v"(voff));
+        if (s + DL < NS)
+            issue(s + DL < NS ? s + DL : s);
+        if (s + DW < NS)
+            W[s + DW < NS ? s + DW : s] = weights(s + DW);
+    }
+    // (opaque lane index: the per-group lane predicates are cheaper than the registers that would
+    // hold them across the FFT phase)
+    int lp = ln;
+    asm volatile("" : "+v"(lp));
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc += ra[s];
+        // (opaque: the group predicates derived from it are SALU work per frame, not a dozen hoisted
+        // scalars per step that would spill to VGPR lanes)
+        int info = sch.step_info[s];
+        asm volatile("" : "+s"(info));
+        if (info & 1) {                              // last step of a group: sum its K-slices, emit
+            const int pl = (info >> 1) & 7, base = info >> 4;
+            if (pl >= 1) {
+                auto xa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+                acc = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
+            }
+            if (pl >= 2) {
+                auto xa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+                acc = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
+            }
+            const int mel = base + (lp & ((64 >> pl) - 1));
+            if ((lp >> (6 - pl)) == 0 && mel < kMelMaxMels)
+                stage[mel] = acc;
+            acc = 0.0f;
+        }
+    }
+}
 // Mel values of the wave's F frames (stage[128 f + mel], written by mel_reduce) ->
 // 10 log10(max(., floor)) -> rows of n_mels floats, two coalesced dword stores per row.
 template <int F>
@@ -1301,7 +1407,7 @@ __device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
     pk_dft8(v);
 }
 
-template <int OUT, bool WIDE>
+template <int OUT, bool WIDE, int NS = 0>   // NS: steps of the streamed mel schedule (kLogMelR only)
 __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
@@ -1519,7 +1625,10 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
                     rotate_wave_priority3(prio_step + 2);
-                    mel_reduce<1>(lrow, NB, melpar, sch, melstage);
+                    if (OUT == kLogMelR)
+                        mel_reduce_streamed<(NS > 0 ? NS : 2)>(lds_addr(lrow), mel_par, sch, melstage);
+                    else
+                        mel_reduce<1>(lrow, NB, melpar, sch, melstage);
                     mel_store<1>(melstage, sch, log_floor, row, nullptr, false);
                 } else if (WIDE) {
                     const int sh = (row0 + t) & 3;     // 1025 = 1 (mod 4): same shift rule as 513
@@ -2392,7 +2501,7 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     }
 }
 
-template <int K>
+template <int K, int NS = 0>
 static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
@@ -2403,15 +2512,15 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
     static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
     static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
-        cached_grid = persistent_grid(stft_wave2048_kernel<K, true>, lds);
+        cached_grid = persistent_grid(stft_wave2048_kernel<K, true, NS>, lds);
         cached_lds = lds;
     }
     const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
     if (wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     return hipGetLastError();
 }
@@ -2425,6 +2534,8 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
+    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelStreamMaxSteps))
+        return hipErrorInvalidValue;
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
@@ -2437,6 +2548,12 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
         return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     case kLogMel:
         return launch_wave2048_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+    case kLogMelR:   // the instantiation with the fewest steps that holds the schedule
+        if (sch.n_steps <= 12)
+            return launch_wave2048_kind<kLogMelR, 12>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        if (sch.n_steps <= 14)
+            return launch_wave2048_kind<kLogMelR, 14>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kLogMelR, 16>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
     default:
         return hipErrorInvalidValue;
     }
