@@ -646,7 +646,11 @@ __device__ __forceinline__ void mel_reduce_streamed(unsigned rows_addr, const fl
 #pragma unroll
     for (int s = 0; s < DL && s < NS; ++s)
         issue(s);
-    float ra[NS];
+    // (opaque lane index for the group ends: their lane predicates are cheaper than the registers
+    // that would hold them across the FFT phase)
+    int lp = ln;
+    asm volatile("" : "+v"(lp));
+    v2f acc2 = {0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         v2f(&c)[2] = P[s];
@@ -667,41 +671,32 @@ __device__ __forceinline__ void mel_reduce_streamed(unsigned rows_addr, const fl
         else
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1])::"memory");
         const v2f w01 = {W[s].x, W[s].y}, w23 = {W[s].z, W[s].w};
-        const v2f r2 = w23 * c[1] + w01 * c[0];
-        ra[s] = r2.x + r2.y;
+        acc2 = w01 * c[0] + acc2;
+        acc2 = w23 * c[1] + acc2;
         // the step ends here: its registers die, the loads of the steps DL / DW ahead reuse them
-        asm volatile("" : "+v"(ra[s]), "+v"(voff));
+        asm volatile("" : "+v"(acc2), "+v"(voff));
         if (s + DL < NS)
             issue(s + DL < NS ? s + DL : s);
         if (s + DW < NS)
             W[s + DW < NS ? s + DW : s] = weights(s + DW);
-    }
-    // (opaque lane index: the per-group lane predicates are cheaper than the registers that would
-    // hold them across the FFT phase)
-    int lp = ln;
-    asm volatile("" : "+v"(lp));
-    float acc = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        acc += ra[s];
-        // (opaque: the group predicates derived from it are SALU work per frame, not a dozen hoisted
-        // scalars per step that would spill to VGPR lanes)
+        // Last step of a group (wave-uniform): the K-slices of a filter sit in adjacent lanes (lane =
+        // filter-in-group * slices + slice): sum them inside the quad, emit, start the next group.
+        // The ds_write is newer than every load still in flight, so the counted waits above only
+        // get more conservative.  (opaque: the predicates are SALU work per frame, not hoisted
+        // scalars that would spill to VGPR lanes)
         int info = sch.step_info[s];
         asm volatile("" : "+s"(info));
-        if (info & 1) {                              // last step of a group: sum its K-slices, emit
+        if (info & 1) {
             const int pl = (info >> 1) & 7, base = info >> 4;
-            if (pl >= 1) {
-                auto xa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
-                acc = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-            }
-            if (pl >= 2) {
-                auto xa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
-                acc = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-            }
-            const int mel = base + (lp & ((64 >> pl) - 1));
-            if ((lp >> (6 - pl)) == 0 && mel < kMelMaxMels)
+            float acc = acc2.x + acc2.y;
+            if (pl >= 1)
+                acc += dpp_update<0xB1, 0xF>(acc, acc);          // quad_perm [1,0,3,2]
+            if (pl >= 2)
+                acc += dpp_update<0x4E, 0xF>(acc, acc);          // quad_perm [2,3,0,1]
+            const int mel = base + (lp >> pl);
+            if ((lp & ((1 << pl) - 1)) == 0 && mel < kMelMaxMels)
                 stage[mel] = acc;
-            acc = 0.0f;
+            acc2 = v2f{0.0f, 0.0f};
         }
     }
 }
