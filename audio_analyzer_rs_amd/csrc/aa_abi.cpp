@@ -319,7 +319,7 @@ bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, int ma
         for (int t = 0; t < trips / 4; ++t, ++s) {
             sch->step_info[s] = (t == trips / 4 - 1 ? 1 : 0) | (pl << 1) | (base << 4);
             for (int lane = 0; lane < 64; ++lane) {
-                const int msub = lane & ((64 >> pl) - 1), h = lane >> (6 - pl), mel = base + msub;
+                const int msub = lane >> pl, h = lane & (parts - 1), mel = base + msub;   // slices in adjacent lanes
                 if (mel >= n_mels)
                     continue;   // weights 0, offset 0
                 const int ks = std::max(0, std::min(lo[mel], nb - parts * trips));

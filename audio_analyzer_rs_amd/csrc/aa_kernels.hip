@@ -511,12 +511,13 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
     // opaque: keeps the NS (2 NS) per-step addresses from being hoisted out of the frame loop
     // into as many long-lived VGPRs
     asm volatile("" : "+v"(rows_addr));
-    // Phase 1 - straight-line code, no branch: the compiler treats the result of a hand-issued
-    // load as available at once, so nothing it could turn into a register copy (a branch merge,
-    // a tied operand it cannot coalesce) may sit between an issue and its wait.  All NS steps
-    // always run (unused steps carry zero weights); every step has its own registers {row a
-    // bins 0-1, 2-3 [, row b bins 0-1, 2-3]}, the loads of D steps are in flight (the phase is
-    // bound by the LDS round trip, not by its FMAs); a step leaves its partial sums in ra / rb.
+    // The compiler treats the result of a hand-issued load as available at once, so nothing it
+    // could turn into a register copy of a load in flight may sit between an issue and its wait:
+    // the code between them is straight-line except for the group ends (wave-uniform branches
+    // that touch only the accumulators).  All NS steps always run (unused steps carry zero
+    // weights); every step has its own registers {row a bins 0-1, 2-3 [, row b bins 0-1, 2-3]},
+    // the loads of D steps are in flight (the phase is bound by the LDS round trip, not by its
+    // FMAs); the sums of a group run through its steps as one FMA chain per frame.
     v2f P[NS][4];
     auto issue = [&](int s) {
         const unsigned aa = rows_addr + mr.off(s);
@@ -527,10 +528,13 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
             P[s][3] = mel_lds_load2<2>(aa + kRowB);
         }
     };
-    float ra[NS], rb[NS];
 #pragma unroll
     for (int s = 0; s < D && s < NS; ++s)
         issue(s);
+    // (opaque lane index for the group ends: see mel_reduce)
+    int lp = lane;
+    asm volatile("" : "+v"(lp));
+    float acc_a = 0.0f, acc_b = 0.0f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         v2f(&c)[4] = P[s];
@@ -550,46 +554,37 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
             mel_lds_wait_step<2, F>(c);
         else
             mel_lds_wait_step<0, F>(c);
-        ra[s] = fmaf(mr.w[s][3], c[1].y, fmaf(mr.w[s][2], c[1].x, fmaf(mr.w[s][1], c[0].y, mr.w[s][0] * c[0].x)));
-        rb[s] = 0.0f;
+        acc_a = fmaf(mr.w[s][3], c[1].y, fmaf(mr.w[s][2], c[1].x, fmaf(mr.w[s][1], c[0].y, fmaf(mr.w[s][0], c[0].x, acc_a))));
         if (F == 2)
-            rb[s] = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, mr.w[s][0] * c[2].x)));
+            acc_b = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, fmaf(mr.w[s][0], c[2].x, acc_b))));
         // keep the step's FMAs here (its registers die, the next issue reuses them): otherwise
         // all steps' loads are hoisted and their bins stay live
         if (F == 2)
-            asm volatile("" : "+v"(ra[s]), "+v"(rb[s]));
+            asm volatile("" : "+v"(acc_a), "+v"(acc_b));
         else
-            asm volatile("" : "+v"(ra[s]));
+            asm volatile("" : "+v"(acc_a));
         if (s + D < NS)
             issue(s + D < NS ? s + D : s);
-    }
-    // Phase 2 - everything has arrived: add the steps of each group, sum its K-slices, emit
-    float acc_a = 0.0f, acc_b = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        acc_a += ra[s];
-        acc_b += rb[s];
-        const int info = sch.step_info[s];
-        if (info & 1) {                              // last step of a group
+        // Last step of a group (wave-uniform): the K-slices of a filter sit in adjacent lanes (lane =
+        // filter-in-group * slices + slice): sum them inside the quad, emit, start the next group.
+        // The ds_writes are newer than every load in flight: the counted waits only get more
+        // conservative.  (opaque: the predicates are SALU work per frame, not hoisted scalars)
+        int info = sch.step_info[s];
+        asm volatile("" : "+s"(info));
+        if (info & 1) {
             const int pl = (info >> 1) & 7, base = info >> 4;
             if (pl >= 1) {
-                auto xa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
-                acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-                if (F == 2) {
-                    auto xb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
-                    acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
-                }
+                acc_a += dpp_update<0xB1, 0xF>(acc_a, acc_a);    // quad_perm [1,0,3,2]
+                if (F == 2)
+                    acc_b += dpp_update<0xB1, 0xF>(acc_b, acc_b);
             }
             if (pl >= 2) {
-                auto xa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_a), __float_as_uint(acc_a), false, false);
-                acc_a = __uint_as_float(xa[0]) + __uint_as_float(xa[1]);
-                if (F == 2) {
-                    auto xb = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc_b), __float_as_uint(acc_b), false, false);
-                    acc_b = __uint_as_float(xb[0]) + __uint_as_float(xb[1]);
-                }
+                acc_a += dpp_update<0x4E, 0xF>(acc_a, acc_a);    // quad_perm [2,3,0,1]
+                if (F == 2)
+                    acc_b += dpp_update<0x4E, 0xF>(acc_b, acc_b);
             }
-            const int mel = base + (lane & ((64 >> pl) - 1));
-            if ((lane >> (6 - pl)) == 0 && mel < kMelMaxMels) {
+            const int mel = base + (lp >> pl);
+            if ((lp & ((1 << pl) - 1)) == 0 && mel < kMelMaxMels) {
                 stage[mel] = acc_a;
                 if (F == 2)
                     stage[stride_b + mel] = acc_b;
