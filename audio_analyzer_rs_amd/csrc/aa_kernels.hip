@@ -469,9 +469,12 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
 // its 4 bins per step (two packed per register): 36 VGPRs at NS = 8 for the kernel's lifetime.
 // (Tried at 2048 with F = 1, NS = 14: 63 more VGPRs push that kernel to two waves per SIMD and
 // the FFT phase loses what the gather gains — 126 us either way — so 2048 keeps mel_reduce.)
+#ifndef AA_MEL_PK
+#define AA_MEL_PK 1        // resident gather: two bins per v_pk_fma_f32 (experiments: 0 = one FMA per bin)
+#endif
 template <int NS>
 struct MelResident {
-    float w[NS][4];
+    v2f w[NS][2];
     unsigned off2[(NS + 1) / 2];   // two 16-bit byte offsets per register
     __device__ __forceinline__ unsigned off(int s) const { return (s & 1) ? off2[s >> 1] >> 16 : off2[s >> 1] & 0xffffu; }
 };
@@ -482,8 +485,8 @@ __device__ __forceinline__ void mel_resident_load(MelResident<NS> &mr, const flo
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            mr.w[s][j] = tab[(s * 5 + j) * 64 + lane];
+        for (int j = 0; j < 2; ++j)
+            mr.w[s][j] = v2f{tab[(s * 5 + 2 * j) * 64 + lane], tab[(s * 5 + 2 * j + 1) * 64 + lane]};
     }
 #pragma unroll
     for (int s = 0; s < NS; s += 2) {
@@ -534,7 +537,7 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
     // (opaque lane index for the group ends: see mel_reduce)
     int lp = lane;
     asm volatile("" : "+v"(lp));
-    float acc_a = 0.0f, acc_b = 0.0f;
+    v2f acc_a = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f};   // even / odd bins of the chain (AA_MEL_PK)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         v2f(&c)[4] = P[s];
@@ -554,9 +557,15 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
             mel_lds_wait_step<2, F>(c);
         else
             mel_lds_wait_step<0, F>(c);
-        acc_a = fmaf(mr.w[s][3], c[1].y, fmaf(mr.w[s][2], c[1].x, fmaf(mr.w[s][1], c[0].y, fmaf(mr.w[s][0], c[0].x, acc_a))));
-        if (F == 2)
-            acc_b = fmaf(mr.w[s][3], c[3].y, fmaf(mr.w[s][2], c[3].x, fmaf(mr.w[s][1], c[2].y, fmaf(mr.w[s][0], c[2].x, acc_b))));
+        if (AA_MEL_PK) {
+            acc_a = mr.w[s][1] * c[1] + (mr.w[s][0] * c[0] + acc_a);
+            if (F == 2)
+                acc_b = mr.w[s][1] * c[3] + (mr.w[s][0] * c[2] + acc_b);
+        } else {
+            acc_a.x = fmaf(mr.w[s][1].y, c[1].y, fmaf(mr.w[s][1].x, c[1].x, fmaf(mr.w[s][0].y, c[0].y, fmaf(mr.w[s][0].x, c[0].x, acc_a.x))));
+            if (F == 2)
+                acc_b.x = fmaf(mr.w[s][1].y, c[3].y, fmaf(mr.w[s][1].x, c[3].x, fmaf(mr.w[s][0].y, c[2].y, fmaf(mr.w[s][0].x, c[2].x, acc_b.x))));
+        }
         // keep the step's FMAs here (its registers die, the next issue reuses them): otherwise
         // all steps' loads are hoisted and their bins stay live
         if (F == 2)
@@ -573,24 +582,25 @@ __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const Me
         asm volatile("" : "+s"(info));
         if (info & 1) {
             const int pl = (info >> 1) & 7, base = info >> 4;
+            float sa = acc_a.x + acc_a.y, sb = acc_b.x + acc_b.y;
             if (pl >= 1) {
-                acc_a += dpp_update<0xB1, 0xF>(acc_a, acc_a);    // quad_perm [1,0,3,2]
+                sa += dpp_update<0xB1, 0xF>(sa, sa);             // quad_perm [1,0,3,2]
                 if (F == 2)
-                    acc_b += dpp_update<0xB1, 0xF>(acc_b, acc_b);
+                    sb += dpp_update<0xB1, 0xF>(sb, sb);
             }
             if (pl >= 2) {
-                acc_a += dpp_update<0x4E, 0xF>(acc_a, acc_a);    // quad_perm [2,3,0,1]
+                sa += dpp_update<0x4E, 0xF>(sa, sa);             // quad_perm [2,3,0,1]
                 if (F == 2)
-                    acc_b += dpp_update<0x4E, 0xF>(acc_b, acc_b);
+                    sb += dpp_update<0x4E, 0xF>(sb, sb);
             }
             const int mel = base + (lp >> pl);
             if ((lp & ((1 << pl) - 1)) == 0 && mel < kMelMaxMels) {
-                stage[mel] = acc_a;
+                stage[mel] = sa;
                 if (F == 2)
-                    stage[stride_b + mel] = acc_b;
+                    stage[stride_b + mel] = sb;
             }
-            acc_a = 0.0f;
-            acc_b = 0.0f;
+            acc_a = v2f{0.0f, 0.0f};
+            acc_b = v2f{0.0f, 0.0f};
         }
     }
 }
