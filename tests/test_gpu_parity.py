@@ -326,8 +326,8 @@ def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, monkey
     monkeypatch.setenv("AA_MEL_GEMM", "1")
     gemm = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
     monkeypatch.delenv("AA_MEL_GEMM")
-    # the 1024 kernel keeps the weights in registers when the schedule fits; the other variant
-    # computes them from the triangle edges for every frame
+    # table-driven weights when the schedule fits (1024: resident in registers, 2048: streamed from a
+    # per-lane table every frame); the other variant computes them from the triangle edges for every frame
     monkeypatch.setenv("AA_MEL_NO_RESIDENT", "1")
     alt = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
     monkeypatch.delenv("AA_MEL_NO_RESIDENT")
@@ -340,6 +340,23 @@ def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, monkey
     L = 10.0 * np.log10(M)
     near = L >= L.max(axis=1, keepdims=True) - 40.0
     assert np.max(np.abs(fused - gemm)[near]) < 1e-3
+
+
+@pytest.mark.parametrize("sr,n_mels", [(16000, 64), (16000, 128), (22050, 80), (44100, 80), (44100, 128),
+                                        (96000, 64), (96000, 128), (22050, 40), (8000, 24)])
+def test_streamed_mel_schedules_2048(aa, oracle_mod, torch_mod, sr, n_mels):
+    """The 2048 kernel streams the filter weights from a per-lane table when the schedule fits 16
+    steps of 4 bins (instantiations for 12 / 14 / 16 steps: the sample rates and band counts here
+    land on each of them) and falls back to weights rebuilt from the triangle edges otherwise
+    (40 bands at 22.05 kHz need 18 steps).  All against the float64 definition."""
+    n, hop = 2048, 512
+    x = aa.signals.synth_corpus(11, n + 333 * hop)          # ragged last chunk included
+    got = aa.Stft(n, hop, output="logmel", sample_rate=sr, n_mels=n_mels)(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+    tr = oracle_mod.truth
+    P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+    M = np.maximum(P @ tr.mel_filterbank(sr, n, n_mels).T, 1e-10)
+    assert got.shape == M.shape == (334, n_mels)
+    assert nerr(10.0 ** (got.astype(np.float64) / 10.0), M).max() < 2e-5
 
 
 def test_mfcc_sine_and_chirp(aa, oracle_mod, torch_mod):
