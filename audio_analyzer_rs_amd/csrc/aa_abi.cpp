@@ -400,29 +400,30 @@ bool build_mel_streamed(const std::vector<double> &w, int nb, int n_mels, std::v
 // aa_kernels.hip above stft_wave2048_kernel).
 void build_wave2048_table(const float *window, std::vector<float> *tab)
 {
-    tab->assign((size_t)aa::kWave2048Rows * 64, 0.0f);
+    tab->assign((size_t)aa::kWave2048TableDwords, 0.0f);
     float *T = tab->data();
+    float *W4 = T + (size_t)aa::kWave2048Rows * 64, *C4 = W4 + 8 * 64 * 4, *A4 = C4 + 8 * 64 * 4;   // streamed by the ring variant
     for (int lane = 0; lane < 64; ++lane) {
         const int b = lane >> 3;
         for (int j = 0; j < 8; ++j)
             for (int c = 0; c < 4; ++c)
-                T[(4 * j + c) * 64 + lane] = 0.5f * window[4 * (64 * j + lane) + c];
+                W4[(j * 64 + lane) * 4 + c] = T[(4 * j + c) * 64 + lane] = 0.5f * window[4 * (64 * j + lane) + c];
         for (int k = 1; k < 8; ++k) {
             double aA = -2.0 * kPi * (double)(lane * k) / 512.0;
-            T[(32 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aA);
-            T[(33 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aA);
+            A4[((k >> 1) * 64 + lane) * 4 + 2 * (k & 1) + 0] = T[(32 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aA);
+            A4[((k >> 1) * 64 + lane) * 4 + 2 * (k & 1) + 1] = T[(33 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aA);
             double aB = -2.0 * kPi * (double)(b * k) / 64.0;
-            T[(46 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aB);
-            T[(47 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aB);
+            A4[((4 + (k >> 1)) * 64 + lane) * 4 + 2 * (k & 1) + 0] = T[(46 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(aB);
+            A4[((4 + (k >> 1)) * 64 + lane) * 4 + 2 * (k & 1) + 1] = T[(47 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(aB);
         }
         for (int j = 0; j < 8; ++j) {
             const int kk = lane + 64 * j;
             double ac = -2.0 * kPi * (double)kk / 1024.0;
-            T[(60 + 2 * j) * 64 + lane] = (float)std::cos(ac);
-            T[(61 + 2 * j) * 64 + lane] = (float)std::sin(ac);
+            C4[((j >> 1) * 64 + lane) * 4 + 2 * (j & 1) + 0] = T[(60 + 2 * j) * 64 + lane] = (float)std::cos(ac);
+            C4[((j >> 1) * 64 + lane) * 4 + 2 * (j & 1) + 1] = T[(61 + 2 * j) * 64 + lane] = (float)std::sin(ac);
             double th = 2.0 * kPi * (double)kk / 2048.0;
-            T[(76 + 2 * j) * 64 + lane] = (float)(-std::sin(th));
-            T[(77 + 2 * j) * 64 + lane] = (float)(-std::cos(th));
+            C4[((4 + (j >> 1)) * 64 + lane) * 4 + 2 * (j & 1) + 0] = T[(76 + 2 * j) * 64 + lane] = (float)(-std::sin(th));
+            C4[((4 + (j >> 1)) * 64 + lane) * 4 + 2 * (j & 1) + 1] = T[(77 + 2 * j) * 64 + lane] = (float)(-std::cos(th));
         }
     }
 }

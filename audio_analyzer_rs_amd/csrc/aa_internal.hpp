@@ -97,6 +97,10 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
 
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;
+// behind the rows: the float4 tables the ring variant streams per frame - [8][64] window quadruples,
+// [4][64] pairs of combine twiddles, [4][64] pairs of split twiddles, [4][64] + [4][64] pairs of pass-A /
+// pass-B twiddles
+constexpr int kWave2048TableDwords = kWave2048Rows * 64 + 3 * 8 * 64 * 4;
 inline int64_t wave2048_lds_dwords(int frames_per_wg, int hop, bool mel = false)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 2048;
@@ -107,6 +111,13 @@ inline size_t wave2048_lds_bytes(int frames_per_wg, int hop, bool mel = false)
     return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop, mel);
 }
 // kLogMelR: mel_par is the streamed table (kMelStreamTableDwords), sched->n_steps <= kMelStreamMaxSteps.
+// Ring variant (hop 512, 4 frames per chunk): 22 blocks of 256 floats + the four scratch areas
+// [+ the mel stage (kLogMelR: 2) or the parameter table and the stage (kLogMel: 1)].
+inline size_t wave2048_ring_lds_bytes(int mel_kind)
+{
+    return sizeof(float) * (size_t)(22 * 256 + 4 * kWave1024ScratchDwords +
+                                    (mel_kind == 2 ? 4 * kMelStageDwords : mel_kind == 1 ? kMelLdsDwords : 0));
+}
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,

@@ -754,6 +754,9 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_ILV
 #define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
 #endif
+#ifndef AA_V_SHARE
+#define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
+#endif
 #ifndef AA_V_SPLIT
 #define AA_V_SPLIT 1       // uneven chunk runs: the remainder goes to the workgroups dispatched first
 #endif
@@ -959,13 +962,15 @@ void stft_wave1024_kernel(
             v[3] = lds_read_b64<1536>(fr); v[4] = lds_read_b64<2048>(fr); v[5] = lds_read_b64<2560>(fr);
             v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
         };
-        auto pass_a = [&](v2f (&v)[8]) {
-            if (AA_V_WINFMA) {
+        auto pass_a = [&](v2f (&v)[8], bool windowed = false) {
+            if (AA_V_WINFMA && !windowed) {
                 pk_dft8_windowed(v, win);
             } else {
+                if (!windowed) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = v[j] * win[j];
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = v[j] * win[j];
+                }
                 pk_dft8(v);
             }
             pk_twiddle7(v, twA);
@@ -1226,15 +1231,32 @@ void stft_wave1024_kernel(
             if (ta < nf) {
                 const bool vb = tb < nf;   // ragged last chunk: B computes on stale LDS, stores nothing
                 v2f va[8], vbv[8], pa[4], pb[4];
+                // AA_V_SHARE: adjacent frames at hop 256 overlap by six of the eight 128-float blocks a
+                // lane reads (block j of frame b = block j + 2 of frame a, same lane): frame b loads
+                // only its last two blocks and takes the others from frame a's registers
+                const bool share = AA_V_SHARE && PAIR && hop == 256;
                 read_frame(ta, va);
-                read_frame(tb, vbv);
-                lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-                lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                if (share) {
+                    const unsigned frb = buf_addr + 4u * (unsigned)(tb * hop);
+                    vbv[6] = lds_read_b64<3072>(frb);
+                    vbv[7] = lds_read_b64<3584>(frb);
+                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vbv[6]), "+v"(vbv[7])::"memory");
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        vbv[j] = va[j + 2] * win[j];
+                    vbv[6] = vbv[6] * win[6];
+                    vbv[7] = vbv[7] * win[7];
+                } else {
+                    read_frame(tb, vbv);
+                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                }
                 pass_a(va);
                 exchange1(va);
                 if (!(ABL & 1024))
                     rotate_wave_priority(prio_step + 1);
-                pass_a(vbv);
+                pass_a(vbv, share);
                 exchange1(vbv);
                 if (!(ABL & 1024))
                     rotate_wave_priority(prio_step + 2);
@@ -1407,21 +1429,68 @@ __device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
     pk_dft8(v);
 }
 
-template <int OUT, bool WIDE, int NS = 0>   // NS: steps of the streamed mel schedule (kLogMelR only)
-__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft_wave2048_kernel(
+// Hand-issued global load of a lane's 16 bytes at sbase (uniform) + voff (bytes) + OFF; valid after
+// vm_wait_tied8 (same discipline as the hand-issued LDS loads: nothing may copy the register first).
+template <int OFF>
+__device__ __forceinline__ v4f gload4_issue(const float *sbase, unsigned voff)
+{
+    v4f r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>   // at most N newer vector-memory operations in flight
+__device__ __forceinline__ void vm_wait_tied8(v4f (&w)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
+                 : "n"(N)
+                 : "memory");
+}
+// RING (hop 512, 4 frames per chunk - the tuner geometry): FOUR workgroups per CU instead of three.
+//  * staging: one ring of 22 blocks of 256 floats (22.5 KB) instead of two chunk buffers (28.7 KB): a
+//    chunk is blocks [8 i, 8 i + 14) of the workgroup's sample run, block b lives in slot b mod 22, the
+//    8 new blocks of chunk i + 1 overwrite blocks 8 i - 8 .. 8 i - 1 (dead since the chunk-top barrier);
+//    one LDS-DMA instruction moves one block, a wave moves exactly two per full chunk; a frame's eight
+//    ds_read_b128 are eight consecutive blocks.  39.4 KB per workgroup.
+//  * registers: the window (32), the combine and the split twiddles (16 + 16) are not resident but
+//    streamed from the per-lane table (L1 / L2) every frame: <= 128 VGPRs.  The window loads are
+//    issued BEFORE the chunk's LDS-DMA and waited for with a counted vmcnt (vmcnt retires in order:
+//    waiting for a load issued after the DMA would wait for the DMA); the twiddles are fetched in
+//    mid-frame, when the DMA issued at the chunk top has long landed.
+constexpr int kRingBlocks = 22;
+#ifndef AA_R_TWA
+#define AA_R_TWA 1
+#endif
+#ifndef AA_R_TWB
+#define AA_R_TWB 0
+#endif
+#ifndef AA_R_WC
+#define AA_R_WC 0
+#endif
+#ifndef AA_R_TWS
+#define AA_R_TWS 0
+#endif
+template <int OUT, bool WIDE, int NS = 0, bool RING = false>   // NS: steps of the streamed mel schedule (kLogMelR only)
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(RING ? 4 : 3, RING ? 4 : 3)))
+void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
     float log_floor, const float *__restrict__ mel_par, MelSched sch)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = tid & 63, lane0 = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (RING) {
+        hop = 512;
+        frames_per_wg = 4;
+    }
 
     int c0, c1;
     chunk_run(n_chunks, c0, c1);
     const int max_span = (frames_per_wg - 1) * hop + 2048;
-    v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
+    const int stage_dwords = RING ? kRingBlocks * 256 : 2 * max_span;
+    v2f *scr = reinterpret_cast<v2f *>(smem + stage_dwords + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
     // global stores a wave issues for its ONE row of a full 4-frame chunk (see stft_wave1024_kernel)
@@ -1429,8 +1498,8 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                                        : WIDE          ? 5                    // 4 dwordx4 + head / tail dword
                                                        : 17;                  // 17 dwords
     const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
-    float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
-    float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;
+    float *melpar = smem + stage_dwords + 4 * kWave1024ScratchDwords;
+    float *melstage = melpar + (RING && OUT == kLogMelR ? 0 : kMelParTableDwords) + wave * kMelStageDwords;
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
@@ -1452,25 +1521,57 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                     (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
         }
     };
-    if (c0 < c1)
-        stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
+    // RING: blocks [have, need_end) of the workgroup's sample run into their ring slots; wave w moves
+    // blocks have + w, have + w + 4, ..  Returns the number of DMA instructions this wave issued.
+    int have = 0;
+    const float *src_wg = src_chunk + 4 * lane;
+    auto ring_dma = [&](int need_end) {
+        int issued = 0;
+        for (int b = have + wave; b < need_end; b += 4, ++issued)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src_wg + 256 * b),
+                (__attribute__((address_space(3))) void *)(smem + 256 * (b % kRingBlocks)), 16, 0, AA_V_DMA_AUX);
+        have = need_end;
+        return issued;
+    };
+    if (c0 < c1) {
+        const int nfc = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        if (RING)
+            ring_dma(2 * (nfc - 1) + 8);
+        else
+            stage(src_chunk, nfc, 0);
+    }
 
     v4f win[8];
     v2f twA[8], twB[8], wc[8], tws[8];
+    if (!RING) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
-                     tab[(4 * j + 3) * 64 + lane]};
+        for (int j = 0; j < 8; ++j)
+            win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
+                         tab[(4 * j + 3) * 64 + lane]};
+    }
+    // RING: which twiddle sets stay resident (the others are streamed per frame)
+    constexpr bool kResA = !RING || AA_R_TWA, kResB = !RING || AA_R_TWB, kResC = !RING || AA_R_WC,
+                   kResS = !RING || AA_R_TWS;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
-        twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
+        if (kResA)
+            twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
+        if (kResB)
+            twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        wc[j] = v2f{tab[(60 + 2 * j) * 64 + lane], tab[(61 + 2 * j) * 64 + lane]};
-        tws[j] = v2f{tab[(76 + 2 * j) * 64 + lane], tab[(77 + 2 * j) * 64 + lane]};
+        if (kResC)
+            wc[j] = v2f{tab[(60 + 2 * j) * 64 + lane], tab[(61 + 2 * j) * 64 + lane]};
+        if (kResS)
+            tws[j] = v2f{tab[(76 + 2 * j) * 64 + lane], tab[(77 + 2 * j) * 64 + lane]};
     }
+    // RING: the streamed per-lane tables behind the 92 rows: [8][64] float4 of the window, then [4][64]
+    // float4 each of: two combine twiddles (j = 2 i, 2 i + 1), two split twiddles, two pass-A twiddles
+    // (k = 2 i, 2 i + 1; k = 0 unused), two pass-B twiddles
+    const float *win4 = tab + kWave2048Rows * 64, *ct4 = win4 + 8 * 64 * 4, *ab4 = ct4 + 8 * 64 * 4;
+    v4f twA4[4];                                     // RING: pass-A twiddles as loaded
 
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
@@ -1495,31 +1596,115 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
         else
             rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        int n_dma = -1;                                  // RING: DMA instructions issued behind the window loads
+        if (RING && wave < nf) {
+            unsigned voff = 16u * (unsigned)lane;
+            asm volatile("" : "+v"(voff));               // (not a loop invariant worth a register)
+            win[0] = gload4_issue<0>(win4, voff);
+            win[1] = gload4_issue<1024>(win4, voff);
+            win[2] = gload4_issue<2048>(win4, voff);
+            win[3] = gload4_issue<3072>(win4, voff);
+            win[4] = gload4_issue<0>(win4 + 1024, voff);
+            win[5] = gload4_issue<1024>(win4 + 1024, voff);
+            win[6] = gload4_issue<2048>(win4 + 1024, voff);
+            win[7] = gload4_issue<3072>(win4 + 1024, voff);
+            if (!kResA) {
+                twA4[0] = gload4_issue<0>(ab4, voff);
+                twA4[1] = gload4_issue<1024>(ab4, voff);
+                twA4[2] = gload4_issue<2048>(ab4, voff);
+                twA4[3] = gload4_issue<3072>(ab4, voff);
+            }
+        }
         if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
-            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+            const int nfn = nleft < frames_per_wg ? nleft : frames_per_wg;
+            if (RING)
+                n_dma = ring_dma(8 * (c - c0 + 1) + 2 * (nfn - 1) + 8);
+            else
+                stage(src_chunk + src_stride, nfn, cur ^ 1);
         }
         const int row0 = (c * frames_per_wg) & 31;
         const v4f *buf = reinterpret_cast<const v4f *>(smem + cur * max_span) + lane;
 
         for (int t = wave; t < nf; t += 4) {
-            const v4f *fr = buf + ((t * hop) >> 2);
+            // RING: per-lane addresses come from opaque copies of the lane index - as loop invariants
+            // they are hoisted out of the chunk loop, held across the FFT phases and spilled
+            int lane = lane0;
+            if (RING)
+                asm volatile("" : "+v"(lane));
             v2f e[8], o[8];
+            if (RING) {
+                // frame t starts at block 8 (c - c0) + 2 t; read j is block + j
+                const int s0 = (8 * (c - c0) + 2 * t) % kRingBlocks;
+                v4f raw[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v4f sx = fr[64 * j] * win[j];
-                e[j] = v2f{sx.x, sx.y};
-                o[j] = v2f{sx.z, sx.w};
+                for (int j = 0; j < 8; ++j) {
+                    const int sj = s0 + j < kRingBlocks ? s0 + j : s0 + j - kRingBlocks;
+                    raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
+                }
+                if (n_dma == 2)
+                    vm_wait_tied8<2>(win);
+                else if (n_dma == 1)
+                    vm_wait_tied8<1>(win);
+                else
+                    vm_wait_tied8<0>(win);
+                if (!kResA) {
+                    asm volatile("" : "+v"(twA4[0]), "+v"(twA4[1]), "+v"(twA4[2]), "+v"(twA4[3])::"memory");   // same wait
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        twA[2 * i] = v2f{twA4[i].x, twA4[i].y};
+                        twA[2 * i + 1] = v2f{twA4[i].z, twA4[i].w};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v4f sx = raw[j] * win[j];
+                    e[j] = v2f{sx.x, sx.y};
+                    o[j] = v2f{sx.z, sx.w};
+                }
+            } else {
+                const v4f *fr = buf + ((t * hop) >> 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v4f sx = fr[64 * j] * win[j];
+                    e[j] = v2f{sx.x, sx.y};
+                    o[j] = v2f{sx.z, sx.w};
+                }
             }
+            int ln = lane;
+            if (!kResB) {
+                // pass-B twiddles of this frame: in flight during pass A
+                asm volatile("" : "+v"(ln));
+                const v4f *bp = reinterpret_cast<const v4f *>(ab4) + 4 * 64 + ln;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4f q = bp[64 * i];
+                    twB[2 * i] = v2f{q.x, q.y};
+                    twB[2 * i + 1] = v2f{q.z, q.w};
+                }
+            }
+            v2f *e1w = RING ? scr + 66 * (lane & 7) + (lane >> 3) : e1_wr;
+            const v4f *e1r = RING ? reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3)) : e1_rd;
             fft512_pass_a(e, twA);
-            fft512_exchange1(e, e1_wr, e1_rd);
+            fft512_exchange1(e, e1w, e1r);
             fft512_pass_a(o, twA);
-            fft512_exchange1(o, e1_wr, e1_rd);
+            fft512_exchange1(o, e1w, e1r);
             if (MEL)
                 rotate_wave_priority3(prio_step + 1);
             else
                 rotate_wave_priority(prio_step + 1);
             fft512_pass_bc(e, twB);
+            if (!kResC) {
+                // combine twiddles of this frame: in flight during passes B and C of the odd half
+                asm volatile("" : "+v"(ln));
+                const v4f *cp = reinterpret_cast<const v4f *>(ct4) + ln;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f q = cp[64 * j];
+                    wc[2 * j] = v2f{q.x, q.y};
+                    wc[2 * j + 1] = v2f{q.z, q.w};
+                }
+            }
             fft512_pass_bc(o, twB);
             // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
             v2f zl[8], zh[8];
@@ -1528,6 +1713,17 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
                 v2f tt = pk_cmul(o[j], wc[j]);
                 zl[j] = e[j] + tt;
                 zh[j] = e[j] - tt;
+            }
+            if (!kResS) {
+                // split twiddles: in flight during the strip round trip
+                asm volatile("" : "+v"(ln));
+                const v4f *sp = reinterpret_cast<const v4f *>(ct4) + 4 * 64 + ln;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f q = sp[64 * j];
+                    tws[2 * j] = v2f{q.x, q.y};
+                    tws[2 * j + 1] = v2f{q.z, q.w};
+                }
             }
             // strip[i] = Z[512 + i], i = 0..511; strip[512] = Z[1024] := Z[0]
 #pragma unroll
@@ -1541,6 +1737,8 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
             for (int j = 0; j < 8; ++j)
                 prt[j] = scr[512 - (lane + 64 * j)];
             __builtin_amdgcn_wave_barrier();
+            if (RING)
+                asm volatile("" : "+v"(lane));
 
             float *row = out_chunk + t * COLS;
             v2f xk[8], xm[8];
@@ -2508,19 +2706,37 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
                                        const MelSched &sch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave2048_lds_bytes(frames_per_wg, hop, K == kLogMel || K == kLogMelR);
-    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
-    static thread_local size_t cached_lds = 0;
-    if (cached_grid == 0 || cached_lds != lds) {
-        cached_grid = persistent_grid(stft_wave2048_kernel<K, true, NS>, lds);
-        cached_lds = lds;
+    constexpr int kMelKind = K == kLogMelR ? 2 : K == kLogMel ? 1 : 0;
+    // The ring variant (four workgroups per CU, constants streamed) pays for the complex rows of the
+    // tuner geometry only: 113.6 -> 107.6-111.0 us; the magnitude kernel loses 3-6 % (the streamed
+    // constants occupy the L1 path: 20 KB per frame at 64 B per clock and CU) and the fused mel variants
+    // cannot reach four workgroups per CU with their stage in LDS.  AA_W2048_RING=0/1: experiments.
+    constexpr bool kRingBuilt = K == kComplex;
+    bool ring = kRingBuilt && hop == 512 && frames_per_wg == 4;
+    if (const char *e = getenv("AA_W2048_RING"))
+        ring = ring && atoi(e) != 0;
+    size_t lds = ring ? wave2048_ring_lds_bytes(kMelKind) : wave2048_lds_bytes(frames_per_wg, hop, kMelKind != 0);
+    if (const char *e = getenv("AA_LDS_PAD"))           // experiments: fewer resident workgroups per CU
+        lds += (size_t)atoi(e);
+    static thread_local int cached_grid[2] = {0, 0};   // per thread: plans of different threads are independent
+    static thread_local size_t cached_lds[2] = {0, 0};
+    if (cached_grid[ring] == 0 || cached_lds[ring] != lds) {
+        cached_grid[ring] = ring ? persistent_grid(stft_wave2048_kernel<K, true, NS, kRingBuilt>, lds)
+                                 : persistent_grid(stft_wave2048_kernel<K, true, NS, false>, lds);
+        cached_lds[ring] = lds;
     }
-    const dim3 grid((unsigned)(cached_grid < chunks ? cached_grid : chunks)), block(kWave1024Threads);
-    if (wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS>), grid, block, lds, stream, x, out, table,
+    const dim3 grid((unsigned)(cached_grid[ring] < chunks ? cached_grid[ring] : chunks)), block(kWave1024Threads);
+    if (ring && wide)
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, kRingBuilt>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+    else if (ring)
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, kRingBuilt>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+    else if (wide)
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, false>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, false>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     return hipGetLastError();
 }
