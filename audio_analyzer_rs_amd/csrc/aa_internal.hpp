@@ -111,11 +111,11 @@ inline size_t wave2048_lds_bytes(int frames_per_wg, int hop, bool mel = false)
     return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop, mel);
 }
 // kLogMelR: mel_par is the streamed table (kMelStreamTableDwords), sched->n_steps <= kMelStreamMaxSteps.
-// Ring variant (hop 512, 4 frames per chunk): 22 blocks of 256 floats + the four scratch areas
+// Ring variants (hop 512, 4 frames per chunk): `blocks` blocks of 256 floats + the four scratch areas
 // [+ the mel stage (kLogMelR: 2) or the parameter table and the stage (kLogMel: 1)].
-inline size_t wave2048_ring_lds_bytes(int mel_kind)
+inline size_t wave2048_ring_lds_bytes(int blocks, int mel_kind)
 {
-    return sizeof(float) * (size_t)(22 * 256 + 4 * kWave1024ScratchDwords +
+    return sizeof(float) * (size_t)(blocks * 256 + 4 * kWave1024ScratchDwords +
                                     (mel_kind == 2 ? 4 * kMelStageDwords : mel_kind == 1 ? kMelLdsDwords : 0));
 }
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,

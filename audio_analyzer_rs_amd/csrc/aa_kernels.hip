@@ -1470,8 +1470,14 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_R_TWS
 #define AA_R_TWS 0
 #endif
-template <int OUT, bool WIDE, int NS = 0, bool RING = false>   // NS: steps of the streamed mel schedule (kLogMelR only)
-__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(RING ? 4 : 3, RING ? 4 : 3)))
+// RING == 2: the ring alone, 30 blocks, with the LDS-DMA running TWO chunks ahead (three workgroups per
+// CU, constants resident as in the plain variant).  With four frames per chunk and three workgroups per
+// CU a chunk lasts ~1.7 us - about one HBM round trip under load - so the one-chunk-ahead DMA of the
+// plain variant arrives late whenever the samples come from HBM rather than the Infinity Cache; the
+// fused mel variants, whose streamed weights are waited for in mid-frame (vmcnt retires in order: that
+// wait includes every older DMA), issue the DMA behind the gather instead of at the chunk top.
+template <int OUT, bool WIDE, int NS = 0, int RING = 0>   // NS: steps of the streamed mel schedule (kLogMelR only)
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(RING == 1 ? 4 : 3, RING == 1 ? 4 : 3)))
 void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
@@ -1481,6 +1487,9 @@ void stft_wave2048_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, lane0 = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool STREAM = RING == 1;               // constants streamed, four workgroups per CU
+    constexpr int RB = RING == 2 ? 30 : kRingBlocks;  // ring blocks
+    constexpr int DEPTH = RING == 2 ? 2 : 1;         // chunks the DMA runs ahead
     if (RING) {
         hop = 512;
         frames_per_wg = 4;
@@ -1489,7 +1498,7 @@ void stft_wave2048_kernel(
     int c0, c1;
     chunk_run(n_chunks, c0, c1);
     const int max_span = (frames_per_wg - 1) * hop + 2048;
-    const int stage_dwords = RING ? kRingBlocks * 256 : 2 * max_span;
+    const int stage_dwords = RING ? RB * 256 : 2 * max_span;
     v2f *scr = reinterpret_cast<v2f *>(smem + stage_dwords + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
@@ -1530,29 +1539,36 @@ void stft_wave2048_kernel(
         for (int b = have + wave; b < need_end; b += 4, ++issued)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src_wg + 256 * b),
-                (__attribute__((address_space(3))) void *)(smem + 256 * (b % kRingBlocks)), 16, 0, AA_V_DMA_AUX);
-        have = need_end;
+                (__attribute__((address_space(3))) void *)(smem + 256 * (b % RB)), 16, 0, AA_V_DMA_AUX);
+        if (need_end > have)
+            have = need_end;
         return issued;
     };
+    // last block + 1 of chunk ci (relative to c0) of this workgroup's run; `have` when there is no such chunk
+    const int run_frames = (c1 - c0) * 4 < frames_left ? (c1 - c0) * 4 : frames_left;
+    auto blocks_end = [&](int ci) {
+        const int left = run_frames - 4 * ci;
+        return left <= 0 ? have : 8 * ci + 2 * ((left < 4 ? left : 4) - 1) + 8;
+    };
     if (c0 < c1) {
-        const int nfc = frames_left < frames_per_wg ? frames_left : frames_per_wg;
-        if (RING)
-            ring_dma(2 * (nfc - 1) + 8);
-        else
-            stage(src_chunk, nfc, 0);
+        if (RING) {
+            for (int k = 0; k < DEPTH; ++k)
+                ring_dma(blocks_end(k));
+        } else
+            stage(src_chunk, frames_left < frames_per_wg ? frames_left : frames_per_wg, 0);
     }
 
     v4f win[8];
     v2f twA[8], twB[8], wc[8], tws[8];
-    if (!RING) {
+    if (!STREAM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
                          tab[(4 * j + 3) * 64 + lane]};
     }
     // RING: which twiddle sets stay resident (the others are streamed per frame)
-    constexpr bool kResA = !RING || AA_R_TWA, kResB = !RING || AA_R_TWB, kResC = !RING || AA_R_WC,
-                   kResS = !RING || AA_R_TWS;
+    constexpr bool kResA = !STREAM || AA_R_TWA, kResB = !STREAM || AA_R_TWB, kResC = !STREAM || AA_R_WC,
+                   kResS = !STREAM || AA_R_TWS;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         if (kResA)
@@ -1576,13 +1592,25 @@ void stft_wave2048_kernel(
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
 
+    int dma_prev = 0;                                   // RING == 2: DMA instructions of the last round
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
         // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
         // row in the previous (full) chunk, after issuing this chunk's DMA loads
         if (c == c0 || frames_per_wg != 4)
             wait_vmcnt_le<0>();
-        else if (MEL && sch.n_mels > 64)
+        else if (RING == 2) {
+            // the blocks of this chunk were issued two DMA rounds ago: behind them sit the stores of
+            // two (full) chunks and the two DMA instructions of the last round
+            if (c - c0 < 2 || dma_prev != 2)
+                wait_vmcnt_le<0>();
+            else if (MEL && sch.n_mels > 64)             // (DMA behind the stores: one chunk's stores + one round)
+                wait_vmcnt_le<2 + 2>();
+            else if (MEL)
+                wait_vmcnt_le<1 + 2>();
+            else
+                wait_vmcnt_le<2 * kRowStoresPerChunk + 2>();
+        } else if (MEL && sch.n_mels > 64)
             wait_vmcnt_le<2>();
         else if (MEL)
             wait_vmcnt_le<1>();
@@ -1596,8 +1624,8 @@ void stft_wave2048_kernel(
         else
             rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
-        int n_dma = -1;                                  // RING: DMA instructions issued behind the window loads
-        if (RING && wave < nf) {
+        int n_dma = -1;                                  // STREAM: DMA instructions issued behind the window loads
+        if (STREAM && wave < nf) {
             unsigned voff = 16u * (unsigned)lane;
             asm volatile("" : "+v"(voff));               // (not a loop invariant worth a register)
             win[0] = gload4_issue<0>(win4, voff);
@@ -1615,13 +1643,12 @@ void stft_wave2048_kernel(
                 twA4[3] = gload4_issue<3072>(ab4, voff);
             }
         }
-        if (c + 1 < c1) {
+        if (RING) {
+            if (!(RING == 2 && MEL))                     // (those: behind the gather)
+                dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
+        } else if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
-            const int nfn = nleft < frames_per_wg ? nleft : frames_per_wg;
-            if (RING)
-                n_dma = ring_dma(8 * (c - c0 + 1) + 2 * (nfn - 1) + 8);
-            else
-                stage(src_chunk + src_stride, nfn, cur ^ 1);
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
         const int row0 = (c * frames_per_wg) & 31;
         const v4f *buf = reinterpret_cast<const v4f *>(smem + cur * max_span) + lane;
@@ -1630,19 +1657,20 @@ void stft_wave2048_kernel(
             // RING: per-lane addresses come from opaque copies of the lane index - as loop invariants
             // they are hoisted out of the chunk loop, held across the FFT phases and spilled
             int lane = lane0;
-            if (RING)
+            if (STREAM)
                 asm volatile("" : "+v"(lane));
             v2f e[8], o[8];
             if (RING) {
                 // frame t starts at block 8 (c - c0) + 2 t; read j is block + j
-                const int s0 = (8 * (c - c0) + 2 * t) % kRingBlocks;
+                const int s0 = (8 * (c - c0) + 2 * t) % RB;
                 v4f raw[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int sj = s0 + j < kRingBlocks ? s0 + j : s0 + j - kRingBlocks;
+                    const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
                     raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
                 }
-                if (n_dma == 2)
+                if (!STREAM) {
+                } else if (n_dma == 2)
                     vm_wait_tied8<2>(win);
                 else if (n_dma == 1)
                     vm_wait_tied8<1>(win);
@@ -1683,8 +1711,8 @@ void stft_wave2048_kernel(
                     twB[2 * i + 1] = v2f{q.z, q.w};
                 }
             }
-            v2f *e1w = RING ? scr + 66 * (lane & 7) + (lane >> 3) : e1_wr;
-            const v4f *e1r = RING ? reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3)) : e1_rd;
+            v2f *e1w = STREAM ? scr + 66 * (lane & 7) + (lane >> 3) : e1_wr;
+            const v4f *e1r = STREAM ? reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3)) : e1_rd;
             fft512_pass_a(e, twA);
             fft512_exchange1(e, e1w, e1r);
             fft512_pass_a(o, twA);
@@ -1737,7 +1765,7 @@ void stft_wave2048_kernel(
             for (int j = 0; j < 8; ++j)
                 prt[j] = scr[512 - (lane + 64 * j)];
             __builtin_amdgcn_wave_barrier();
-            if (RING)
+            if (STREAM)
                 asm volatile("" : "+v"(lane));
 
             float *row = out_chunk + t * COLS;
@@ -1867,6 +1895,8 @@ void stft_wave2048_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (RING == 2 && MEL)
+            dma_prev = ring_dma(blocks_end(c - c0 + DEPTH));
         src_chunk += src_stride;
         out_chunk += out_stride;
         frames_left -= frames_per_wg;
@@ -2707,36 +2737,44 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     constexpr int kMelKind = K == kLogMelR ? 2 : K == kLogMel ? 1 : 0;
-    // The ring variant (four workgroups per CU, constants streamed) pays for the complex rows of the
-    // tuner geometry only: 113.6 -> 107.6-111.0 us; the magnitude kernel loses 3-6 % (the streamed
-    // constants occupy the L1 path: 20 KB per frame at 64 B per clock and CU) and the fused mel variants
-    // cannot reach four workgroups per CU with their stage in LDS.  AA_W2048_RING=0/1: experiments.
-    constexpr bool kRingBuilt = K == kComplex;
-    bool ring = kRingBuilt && hop == 512 && frames_per_wg == 4;
+    // The tuner geometry (hop 512, four frames per chunk) stages through the ring with the DMA two
+    // chunks ahead (RING == 2): log-mel 96.4 -> 88.2 us, magnitudes 82.9 -> 80.1, complex rows 96.3 ->
+    // 91.7 with the samples coming from HBM (two inputs alternating).  The four-workgroup variant with
+    // streamed constants (RING == 1) loses to it everywhere (complex rows 96.4-100.5 us, magnitudes
+    // +3-6 %: the constants occupy the L1 path) and is only built with -DAA_RING_COMPLEX=1.  The mel
+    // variant with arithmetic weights keeps the two chunk buffers (its LDS has no room for the ring).
+    // AA_W2048_RING=0: experiments.
+#ifndef AA_RING_COMPLEX
+#define AA_RING_COMPLEX 2
+#endif
+    constexpr int kRingKind = K == kComplex ? AA_RING_COMPLEX : K == kLogMel ? 0 : 2;   // built for this output kind
+    int ring = hop == 512 && frames_per_wg == 4 ? kRingKind : 0;
     if (const char *e = getenv("AA_W2048_RING"))
-        ring = ring && atoi(e) != 0;
-    size_t lds = ring ? wave2048_ring_lds_bytes(kMelKind) : wave2048_lds_bytes(frames_per_wg, hop, kMelKind != 0);
+        ring = atoi(e) != 0 ? ring : 0;
+    size_t lds = ring ? wave2048_ring_lds_bytes(ring == 2 ? 30 : 22, kMelKind)
+                      : wave2048_lds_bytes(frames_per_wg, hop, kMelKind != 0);
     if (const char *e = getenv("AA_LDS_PAD"))           // experiments: fewer resident workgroups per CU
         lds += (size_t)atoi(e);
+    const int ri = ring ? 1 : 0;
     static thread_local int cached_grid[2] = {0, 0};   // per thread: plans of different threads are independent
     static thread_local size_t cached_lds[2] = {0, 0};
-    if (cached_grid[ring] == 0 || cached_lds[ring] != lds) {
-        cached_grid[ring] = ring ? persistent_grid(stft_wave2048_kernel<K, true, NS, kRingBuilt>, lds)
-                                 : persistent_grid(stft_wave2048_kernel<K, true, NS, false>, lds);
-        cached_lds[ring] = lds;
+    if (cached_grid[ri] == 0 || cached_lds[ri] != lds) {
+        cached_grid[ri] = ring ? persistent_grid(stft_wave2048_kernel<K, true, NS, kRingKind>, lds)
+                               : persistent_grid(stft_wave2048_kernel<K, true, NS, 0>, lds);
+        cached_lds[ri] = lds;
     }
-    const dim3 grid((unsigned)(cached_grid[ring] < chunks ? cached_grid[ring] : chunks)), block(kWave1024Threads);
+    const dim3 grid((unsigned)(cached_grid[ri] < chunks ? cached_grid[ri] : chunks)), block(kWave1024Threads);
     if (ring && wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, kRingBuilt>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, kRingKind>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else if (ring)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, kRingBuilt>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, kRingKind>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else if (wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, false>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, 0>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     else
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, false>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, 0>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
     return hipGetLastError();
 }

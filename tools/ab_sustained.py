@@ -13,25 +13,28 @@ import audio_analyzer_rs_amd as aa
 aa._lib.LIB_PATH = os.path.abspath(sys.argv[1])
 x = aa.signals.synth_corpus(0, 28_800_000)
 xd = torch.from_numpy(x).cuda()
+ALT = int(os.environ.get("AB_ALT", "1"))          # AB_ALT=2: two input / output pairs alternating (stereo, configs[2])
+xs = [xd] + [torch.from_numpy(aa.signals.synth_corpus(0, 28_800_000, seed=54321 + i)).cuda() for i in range(ALT - 1)]
 n_fft, hop, kind = int(os.environ.get("AB_NFFT", "1024")), int(os.environ.get("AB_HOP", "256")), os.environ.get("AB_OUT", "mag")
 extra = dict(n_mels=128) if kind in ("logmel", "mfcc") else {}
 if kind == "mfcc":
     extra["n_mfcc"] = 40
 plan = aa.Stft(n_fft, hop, output=kind, **extra)
 nf = plan.num_frames(xd.shape[0])
-out = torch.empty((nf, plan.cols), dtype=torch.float32, device="cuda")
+outs = [torch.empty((nf, plan.cols), dtype=torch.float32, device="cuda") for _ in range(ALT)]
+out = outs[0]
 st = torch.cuda.current_stream()
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.4:
-    for _ in range(50):
-        plan.execute_device(xd, 0, nf, out=out, stream=st.cuda_stream)
+    for i in range(50):
+        plan.execute_device(xs[i % ALT], 0, nf, out=outs[i % ALT], stream=st.cuda_stream)
     torch.cuda.synchronize()
 res = []
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
-    for _ in range(1000):
-        plan.execute_device(xd, 0, nf, out=out, stream=st.cuda_stream)
+    for i in range(1000):
+        plan.execute_device(xs[i % ALT], 0, nf, out=outs[i % ALT], stream=st.cuda_stream)
     e1.record(st)
     torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1))
