@@ -121,6 +121,35 @@ def test_wave2048_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
     assert nerr(got, tru).max() < TOL_VS_TRUTH
 
 
+@pytest.mark.parametrize("n_frames", [3071, 3073, 3077, 6143, 6146, 9219, 12290])
+@pytest.mark.parametrize("output", ["mag", "complex", "logmel"])
+def test_wave2048_ring_runs_of_few_chunks(aa, oracle_mod, torch_mod, n_frames, output):
+    """The tuner geometry stages its samples through a ring with the LDS-DMA two chunks ahead.  Frame
+    counts around 1, 2, 3 and 4 chunks per persistent workgroup (768 workgroups x 4 frames), ragged
+    tails included: the prologue (two chunks), the first counted waits and the last DMA rounds of
+    a run, EVERY row against the float64 truth; a sub-range that starts inside the buffer as well."""
+    n, hop, sr, n_mels = 2048, 512, 48000, 128
+    x = aa.signals.synth_corpus(23, n + (n_frames - 1) * hop)
+    xd = torch_mod.from_numpy(x).cuda()
+    kw = dict(sample_rate=sr, n_mels=n_mels) if output == "logmel" else {}
+    plan = aa.Stft(n, hop, output=output, **kw)
+    got = plan(xd).cpu().numpy()
+    spec = oracle_mod.truth.stft_complex(x, n, hop, oracle_mod.hann_window(n))
+    if output == "logmel":
+        ref = np.maximum((np.abs(spec) ** 2) @ oracle_mod.truth.mel_filterbank(sr, n, n_mels).T, 1e-10)
+        lin = 10.0 ** (got.astype(np.float64) / 10.0)
+        tol = 2e-5
+    else:
+        ref = spec if output == "complex" else np.abs(spec)
+        lin = got
+        tol = TOL_VS_TRUTH
+    assert lin.shape[0] == n_frames
+    e = nerr(lin, ref)
+    assert e.max() <= tol, (int(np.argmax(e)), float(e.max()))
+    part = plan.execute_device(xd, 5, n_frames - 2).cpu().numpy()
+    assert np.array_equal(part, got[5:n_frames - 2])
+
+
 @pytest.mark.parametrize("hop", [4, 64, 100, 500, 512, 1024, 2048])
 def test_wave2048_hops_and_outputs(aa, oracle_mod, torch_mod, hop):
     n = 2048
