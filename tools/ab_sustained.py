@@ -11,10 +11,11 @@ import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import audio_analyzer_rs_amd as aa
 aa._lib.LIB_PATH = os.path.abspath(sys.argv[1])
-x = aa.signals.synth_corpus(0, 28_800_000)
+NS = int(os.environ.get("AB_SAMPLES", "28800000"))   # AB_SAMPLES: another corpus length
+x = aa.signals.synth_corpus(0, NS)
 xd = torch.from_numpy(x).cuda()
 ALT = int(os.environ.get("AB_ALT", "1"))          # AB_ALT=2: two input / output pairs alternating (stereo, configs[2])
-xs = [xd] + [torch.from_numpy(aa.signals.synth_corpus(0, 28_800_000, seed=54321 + i)).cuda() for i in range(ALT - 1)]
+xs = [xd] + [torch.from_numpy(aa.signals.synth_corpus(0, NS, seed=54321 + i)).cuda() for i in range(ALT - 1)]
 n_fft, hop, kind = int(os.environ.get("AB_NFFT", "1024")), int(os.environ.get("AB_HOP", "256")), os.environ.get("AB_OUT", "mag")
 extra = dict(n_mels=128) if kind in ("logmel", "mfcc") else {}
 if kind == "mfcc":
