@@ -658,6 +658,24 @@ __global__ void downmix_kernel(const float *__restrict__ in, float *__restrict__
     }
 }
 
+// Interleaved stereo, 16-byte-aligned buffers: four frames per lane step - two 16-byte loads
+// (L0 R0 L1 R1 | L2 R2 L3 R3), one nontemporal 16-byte store.  (L + R) * 0.5 is the very value of the
+// general kernel: 0 + L + R is exact in the same order and the halving is exact.
+typedef float dm4 __attribute__((ext_vector_type(4)));
+__global__ void downmix_stereo4_kernel(const dm4 *__restrict__ in, dm4 *__restrict__ out, int64_t n_quads)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const dm4 a = __builtin_nontemporal_load(in + 2 * q), b = __builtin_nontemporal_load(in + 2 * q + 1);
+        dm4 r;
+        r.x = (0.0f + a.x + a.y) / 2.0f;
+        r.y = (0.0f + a.z + a.w) / 2.0f;
+        r.z = (0.0f + b.x + b.y) / 2.0f;
+        r.w = (0.0f + b.z + b.w) / 2.0f;
+        __builtin_nontemporal_store(r, out + q);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
@@ -765,11 +783,26 @@ hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int cha
 {
     if (n_frames <= 0)
         return hipSuccess;
-    int64_t blocks = (n_frames + 255) / 256;
+    // stereo from aligned buffers (the reference's capture format, mod.rs:789-793): the vector kernel
+    // for the whole quads, the general one for the last 0..3 frames
+    int64_t done = 0;
+    if (channels == 2 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 &&
+        n_frames >= 4) {
+        const int64_t quads = n_frames / 4;
+        int64_t blocks = (quads + 255) / 256;
+        if (blocks > 8192)
+            blocks = 8192;
+        hipLaunchKernelGGL(downmix_stereo4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const dm4 *>(in), reinterpret_cast<dm4 *>(out), quads);
+        done = 4 * quads;
+        if (done == n_frames)
+            return hipGetLastError();
+    }
+    int64_t blocks = (n_frames - done + 255) / 256;
     if (blocks > 4096)
         blocks = 4096;
-    hipLaunchKernelGGL(downmix_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, n_frames,
-                       channels);
+    hipLaunchKernelGGL(downmix_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in + done * channels,
+                       out + done, n_frames - done, channels);
     return hipGetLastError();
 }
 

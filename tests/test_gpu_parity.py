@@ -429,6 +429,19 @@ def test_downmix_matches_capture_rule(aa, torch_mod):
         use = min(ch, 2)                                  # mod.rs:784: channels_to_use = min(channels, 2)
         ref = x[:, :use].sum(dim=1) / use if use > 1 else x[:, 0]
         assert torch_mod.allclose(got, ref, rtol=0, atol=1e-7)
+    # stereo takes a vector kernel for whole quads of frames from 16-byte-aligned buffers: same
+    # values, bit for bit, as the general kernel (an unaligned view of the same data goes there)
+    for n in (3, 4, 7, 4096, 100_003):
+        buf = torch_mod.rand(2 * n + 1, generator=g, device="cuda") * 2 - 1
+        inter = buf[: 2 * n].clone()
+        a = aa.downmix(inter, 2)
+        b = aa.downmix(inter.clone(), 2)
+        v = inter.view(n, 2)
+        ref = (v[:, 0] + v[:, 1]) / 2
+        assert torch_mod.equal(a, ref) and torch_mod.equal(a, b)
+        shifted = torch_mod.empty(2 * n + 1, device="cuda")
+        shifted[1:] = inter
+        assert torch_mod.equal(aa.downmix(shifted[1:], 2), ref)        # 4 bytes past an aligned address
 
 
 def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
