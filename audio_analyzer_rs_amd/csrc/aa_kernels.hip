@@ -144,6 +144,20 @@ __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)  // a - conj(b)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// (a.x + b.x, a.x - b.x) and (a.y + b.y, a.y - b.y): the real / imaginary parts of a + b and a - b
+// side by side, so that |a + b|^2 and |a - b|^2 come out of one v_pk_mul + one v_pk_fma.
+__device__ __forceinline__ v2f pk_sum_diff_re(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sum_diff_im(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // The two halves of pk_cmul for loops that want every multiply ahead of every dependent FMA (a
 // dependent pair back to back costs a wait state: the hazard recogniser puts an s_nop between them).
 __device__ __forceinline__ v2f pk_cmul_lo(v2f a, v2f w)
@@ -754,6 +768,12 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_ILV
 #define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
 #endif
+#ifndef AA_V_PKPOW
+#define AA_V_PKPOW 1       // |X[k]|^2 and |X[512-k]|^2 as one packed pair (one v_pk_mul + one v_pk_fma for both)
+#endif
+#ifndef AA_V_PKPOW2048
+#define AA_V_PKPOW2048 AA_V_PKPOW   // the same in stft_wave2048_kernel
+#endif
 #ifndef AA_V_SHARE
 #define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
 #endif
@@ -1049,10 +1069,12 @@ void stft_wave1024_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 st[j] = pk_cmul_hi(so[j], tws[j], st[j]);
+            if (OUT == kComplex || !AA_V_PKPOW) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xk[j] = se[j] + st[j];
-                xm[j] = se[j] - st[j];                           // X[512-k] = conj(xm)
+                for (int j = 0; j < 4; ++j) {
+                    xk[j] = se[j] + st[j];
+                    xm[j] = se[j] - st[j];                       // X[512-k] = conj(xm)
+                }
             }
             if (OUT == kComplex) {
                 if (WIDE) {
@@ -1096,7 +1118,27 @@ void stft_wave1024_kernel(
                 return;
             }
             float mk[4], mm[4];
-            {
+            if (AA_V_PKPOW) {
+                // the real parts of X[k] and X[512-k] in one pair, the imaginary parts in another:
+                // both powers from one packed multiply and one packed FMA
+                v2f re[4], im[4], pw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    re[j] = pk_sum_diff_re(se[j], st[j]);
+                    im[j] = pk_sum_diff_im(se[j], st[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pw[j] = re[j] * re[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pw[j] = im[j] * im[j] + pw[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mk[j] = bin_from_power<OUT>(pw[j].x, log_floor);
+                    mm[j] = bin_from_power<OUT>(pw[j].y, log_floor);
+                }
+            } else {
                 // squares of all eight bins, then the sums, then the roots / logs (same reason)
                 v2f qk[4], qm[4];
 #pragma unroll
@@ -1769,13 +1811,20 @@ void stft_wave2048_kernel(
                 asm volatile("" : "+v"(lane));
 
             float *row = out_chunk + t * COLS;
-            v2f xk[8], xm[8];
+            // complex rows: xk / xm = X[k], conj(X[1024-k]); the other kinds: pw = (|X[k]|^2, |X[1024-k]|^2)
+            // from the real and the imaginary parts of both bins side by side (see pk_sum_diff_re)
+            v2f xk[8], xm[8], pw[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v2f ee = pk_add_conj(zl[j], prt[j]), oo = pk_sub_conj(zl[j], prt[j]);
                 v2f tt = pk_cmul(oo, tws[j]);
-                xk[j] = ee + tt;
-                xm[j] = ee - tt;                       // X[1024-k] = conj(xm)
+                if (OUT == kComplex || !AA_V_PKPOW2048) {
+                    xk[j] = ee + tt;
+                    xm[j] = ee - tt;                   // X[1024-k] = conj(xm)
+                } else {
+                    const v2f re = pk_sum_diff_re(ee, tt), im = pk_sum_diff_im(ee, tt);
+                    pw[j] = im * im + re * re;
+                }
             }
             const v2f z512 = zh[0];                    // lane 0: Z[512]; X[512] = 2 conj(Z[512])
             if (OUT == kComplex && WIDE) {
@@ -1836,8 +1885,13 @@ void stft_wave2048_kernel(
                 float mk[8], mm[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
-                    mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+                    if (AA_V_PKPOW2048) {
+                        mk[j] = bin_from_power<OUT>(pw[j].x, log_floor);
+                        mm[j] = bin_from_power<OUT>(pw[j].y, log_floor);
+                    } else {
+                        mk[j] = bin_value<OUT>(xk[j].x, xk[j].y, log_floor);
+                        mm[j] = bin_value<OUT>(xm[j].x, xm[j].y, log_floor);
+                    }
                 }
                 const float m512 = bin_value<OUT>(2.0f * z512.x, 2.0f * z512.y, log_floor);
                 if (MEL) {
@@ -2114,14 +2168,21 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
                 for (int mu = 0; mu < 4; ++mu) {
                     const v2f e = pk_add_conj(v[mu], prt[mu]), o = pk_sub_conj(v[mu], prt[mu]);
                     const v2f tt = pk_cmul(o, tws[mu]);
-                    const v2f xk = e + tt, xm = e - tt;        // X[128-k] = conj(xm)
                     const int k = lB + 16 * mu;
                     if (OUT == kComplex) {
+                        const v2f xk = e + tt, xm = e - tt;    // X[128-k] = conj(xm)
                         if (live) {
                             reinterpret_cast<v2f *>(grp)[fqB * NB + k] = xk;
                             reinterpret_cast<v2f *>(grp)[fqB * NB + M - k] = v2f{xm.x, -xm.y};
                         }
+                    } else if (AA_V_PKPOW) {
+                        // both powers from one packed multiply and one packed FMA (see pk_sum_diff_re)
+                        const v2f re = pk_sum_diff_re(e, tt), im = pk_sum_diff_im(e, tt);
+                        const v2f pw = im * im + re * re;
+                        mk[mu] = bin_from_power<OUT>(pw.x, log_floor);
+                        mm[mu] = bin_from_power<OUT>(pw.y, log_floor);
                     } else {
+                        const v2f xk = e + tt, xm = e - tt;
                         mk[mu] = bin_value<OUT>(xk.x, xk.y, log_floor);
                         mm[mu] = bin_value<OUT>(xm.x, xm.y, log_floor);
                     }
@@ -2159,16 +2220,25 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             for (int i = 0; i < 5; ++i) {
                 v2f e = pk_add_conj(za[i], zb[i]), o = pk_sub_conj(za[i], zb[i]);
                 v2f tt = pk_cmul(o, tws[i]);
-                v2f xk = e + tt, xm = e - tt;          // X[M-k] = conj(xm)
                 const bool live = pfr[i] < nvalid;
                 if (OUT == kComplex) {
+                    v2f xk = e + tt, xm = e - tt;      // X[M-k] = conj(xm)
                     if (live) {
                         reinterpret_cast<v2f *>(grp)[rlo[i]] = xk;
                         reinterpret_cast<v2f *>(grp)[rhi[i]] = v2f{xm.x, -xm.y};
                     }
                 } else {
-                    const float mk = bin_value<OUT>(xk.x, xk.y, log_floor);
-                    const float mm = bin_value<OUT>(xm.x, xm.y, log_floor);
+                    float mk, mm;
+                    if (AA_V_PKPOW) {
+                        const v2f re = pk_sum_diff_re(e, tt), im = pk_sum_diff_im(e, tt);
+                        const v2f pw = im * im + re * re;
+                        mk = bin_from_power<OUT>(pw.x, log_floor);
+                        mm = bin_from_power<OUT>(pw.y, log_floor);
+                    } else {
+                        v2f xk = e + tt, xm = e - tt;
+                        mk = bin_value<OUT>(xk.x, xk.y, log_floor);
+                        mm = bin_value<OUT>(xm.x, xm.y, log_floor);
+                    }
                     if (pfr[i] < FPW) {
                         scrf[rlo[i]] = mk;
                         scrf[rhi[i]] = mm;
