@@ -108,6 +108,9 @@ SIGNATURES = {
     "aa_stft_execute_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                               ctypes.c_void_p]),
+    "aa_stft_execute_channels_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+                                                       ctypes.c_int64, ctypes.c_void_p]),
     "aa_stft_execute_host": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int64, _f32p]),
     "aa_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "aa_host_unregister": (ctypes.c_int, [ctypes.c_void_p]),

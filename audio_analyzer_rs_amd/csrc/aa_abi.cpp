@@ -1071,8 +1071,61 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
     return p->tabs.pow2 ? "lds_stockham" : "dft";
 }
 
+static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
+                               int64_t frame_begin, int64_t frame_end, float *out_dev, void *stream,
+                               const aa::Channels *chn);
+
 int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
                            int64_t frame_begin, int64_t frame_end, float *out_dev, void *stream)
+{
+    return execute_device_impl(p, samples_dev, n_samples, frame_begin, frame_end, out_dev, stream, nullptr);
+}
+
+int aa_stft_execute_channels_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
+                                    int64_t channel_stride, int32_t n_channels, float *out_dev,
+                                    int64_t out_channel_stride, void *stream)
+{
+    if (!p)
+        return fail(AA_ERR_ARG, "aa_stft_execute_channels_device: plan is NULL");
+    if (n_channels < 1 || n_channels > 1024)
+        return fail(AA_ERR_ARG, "n_channels %d outside 1..1024", (int)n_channels);
+    const int64_t nf = aa_stft_num_frames(p, n_samples);
+    if (n_channels > 1 && (channel_stride < n_samples || out_channel_stride < nf * aa_stft_out_cols(p)))
+        return fail(AA_ERR_ARG, "channel strides (%lld samples, %lld floats) shorter than a channel (%lld, %lld)",
+                    (long long)channel_stride, (long long)out_channel_stride, (long long)n_samples,
+                    (long long)(nf * aa_stft_out_cols(p)));
+    if (nf == 0)
+        return AA_OK;
+    if (!samples_dev || !out_dev)
+        return fail(AA_ERR_ARG, "aa_stft_execute_channels_device: NULL buffer");
+    // One launch when the plan's path is a single wave kernel of n_fft 1024 / 2048 (everything but the
+    // slab paths of MFCC / mel) and the channels keep the 16-byte alignment of the first one
+    const bool mel = p->cfg.output == AA_OUT_LOGMEL || p->cfg.output == AA_OUT_MFCC;
+    const bool single_kernel = (p->wave1024 || p->wave2048) &&
+                               (!mel || (p->fused_mel && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_fused)));
+    const bool aligned = ((channel_stride | out_channel_stride) & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(samples_dev) & 15u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
+    if (n_channels > 1 && single_kernel && aligned) {
+        aa::Channels ch;
+        ch.n = n_channels;
+        ch.in_stride = channel_stride;
+        ch.out_stride = out_channel_stride;
+        return execute_device_impl(p, samples_dev, n_samples, 0, nf, out_dev, stream, &ch);
+    }
+    for (int c = 0; c < n_channels; ++c) {
+        const int rc = execute_device_impl(p, samples_dev + (int64_t)c * channel_stride, n_samples, 0, nf,
+                                           out_dev + (int64_t)c * out_channel_stride, stream, nullptr);
+        if (rc != AA_OK)
+            return rc;
+    }
+    return AA_OK;
+}
+
+// chn != nullptr: only reached for plans whose path is one wave1024 / wave2048 launch (see above)
+static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
+                               int64_t frame_begin, int64_t frame_end, float *out_dev, void *stream,
+                               const aa::Channels *chn)
 {
     if (!p)
         return fail(AA_ERR_ARG, "aa_stft_execute_device: plan is NULL");
@@ -1098,13 +1151,13 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         const float *first = samples_dev + fb * (int64_t)p->cfg.hop;
         if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
-                                       p->frames_per_wg, p->log_floor, st));
+                                       p->frames_per_wg, p->log_floor, st, nullptr, nullptr, nullptr, 0, chn));
         } else if ((p->wave128 || p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave_small(p->cfg.n_fft, kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                          p->frames_per_wg, p->log_floor, st));
         } else if (p->wave2048 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave2048(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
-                                       p->frames_per_wg, p->log_floor, st));
+                                       p->frames_per_wg, p->log_floor, st, nullptr, nullptr, chn));
         } else {
             AA_HIP(aa::launch_generic_forward(p->tabs.pow2, kind, samples_dev, dst, p->d_window,
                                               p->tabs.tw_m, p->tabs.tw_split, p->cfg.n_fft, fb, n,
@@ -1122,11 +1175,12 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
             if (p->wave2048)
                 AA_HIP(aa::launch_wave2048(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
                                            p->d_w1024_tab, fb, n, p->cfg.hop,
-                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched, chn));
             else
                 AA_HIP(aa::launch_wave1024(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
                                            p->d_w1024_tab, fb, n, p->cfg.hop,
-                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched));
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched,
+                                           nullptr, 0, chn));
             return AA_OK;
         };
         if (p->cfg.output == AA_OUT_LOGMEL)
@@ -1134,7 +1188,7 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
         if (p->mfcc_fused) {
             AA_HIP(aa::launch_wave1024(aa::kMfccR, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf,
                                        p->cfg.hop, p->frames_per_wg, p->log_floor, st, p->d_mel_par,
-                                       &p->mel_sched, p->d_dct_lane, p->cfg.n_mfcc));
+                                       &p->mel_sched, p->d_dct_lane, p->cfg.n_mfcc, chn));
             return AA_OK;
         }
         // log-mel rows are small (n_mels floats): one slab of up to 2^18 frames (<= 134 MB) so the

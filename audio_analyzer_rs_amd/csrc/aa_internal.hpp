@@ -88,12 +88,19 @@ inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int mel = 0)
     return sizeof(float) * (size_t)wave1024_lds_dwords(frames_per_wg, hop, mel);
 }
 
+// Several equal-length channels in one launch (aa_stft_execute_channels_device): channel c reads
+// x + c in_stride and writes out + c out_stride (floats, multiples of 4); n = 1: a plain launch.
+struct Channels {
+    int n = 1;
+    int64_t in_stride = 0, out_stride = 0;
+};
 // mel_par / sched are used by kLogMel only (null / nullptr otherwise).
 // dct_tab / n_mfcc: kMfccR only (kMfccTableDwords floats; n_mfcc <= 16 kMfccTiles).
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,
-                           const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0);
+                           const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0,
+                           const Channels *channels = nullptr);
 
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;
@@ -121,7 +128,7 @@ inline size_t wave2048_ring_lds_bytes(int blocks, int mel_kind)
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,
-                           const MelSched *sched = nullptr);
+                           const MelSched *sched = nullptr, const Channels *channels = nullptr);
 
 // ---- several-frames-per-wave kernel for n_fft 256 (onset geometry) and 512 ------------------
 constexpr int kWave256Rows = 50;

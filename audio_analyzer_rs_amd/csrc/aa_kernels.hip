@@ -784,15 +784,37 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 // workgroups dispatched FIRST: the residents of a CU finish in dispatch order even with the priority
 // rotation (64 / 66 / 66 / 68 us for the four dispatch rounds, tools/wg_finish_order.py), so the late
 // ones get the shorter runs: -1.3 % on the sustained 1024 / 256 launch against an even spread.
-__device__ __forceinline__ void chunk_run(int64_t n_chunks, int &c0, int &c1)
+__device__ __forceinline__ void chunk_run(int64_t n_chunks, int &c0, int &c1, int grid, int b)
 {
     if (AA_V_SPLIT) {
-        const int q = (int)(n_chunks / gridDim.x), r = (int)(n_chunks % gridDim.x), b = (int)blockIdx.x;
+        const int q = (int)(n_chunks / grid), r = (int)(n_chunks % grid);
         c0 = b < r ? b * (q + 1) : r * (q + 1) + (b - r) * q;
         c1 = c0 + q + (b < r ? 1 : 0);
     } else {
-        c0 = (int)((int64_t)blockIdx.x * n_chunks / gridDim.x);
-        c1 = (int)((int64_t)(blockIdx.x + 1) * n_chunks / gridDim.x);
+        c0 = (int)((int64_t)b * n_chunks / grid);
+        c1 = (int)((int64_t)(b + 1) * n_chunks / grid);
+    }
+}
+__device__ __forceinline__ void chunk_run(int64_t n_chunks, int &c0, int &c1)
+{
+    chunk_run(n_chunks, c0, c1, (int)gridDim.x, (int)blockIdx.x);
+}
+// Several equal-length channels (streams) in one launch: the grid is n_streams equal groups of
+// workgroups, group s works on x + s in_stride -> out + s out_stride exactly as a launch of its own
+// would (same chunk runs, same results); only the tail of the launch is shared.
+__device__ __forceinline__ void stream_of_block(int n_streams, int64_t in_stride, int64_t out_stride,
+                                                int64_t &in_off, int64_t &out_off, int &grid, int &b)
+{
+    grid = (int)gridDim.x;
+    b = (int)blockIdx.x;
+    in_off = 0;
+    out_off = 0;
+    if (n_streams > 1) {
+        grid /= n_streams;
+        const int s = b / grid;
+        b -= s * grid;
+        in_off = s * in_stride;
+        out_off = s * out_stride;
     }
 }
 #ifndef AA_PRIO_ROTATE
@@ -855,19 +877,26 @@ void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
     float log_floor, const float *__restrict__ mel_par, MelSched sch, const float *__restrict__ dct_tab,
-    int n_mfcc)
+    int n_mfcc, int n_streams, int64_t stream_in_stride, int64_t stream_out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     AA_CLK_BEGIN
+    int vgrid, vblock;
+    {
+        int64_t in_off, out_off;
+        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
+        x += in_off;
+        out += out_off;
+    }
 
     // This workgroup's run of chunks [c0, c1).  Everything per chunk below is 32-bit scalar
     // arithmetic on running pointers (a lone wave issues a scalar instruction only every few
     // cycles: the 64-bit multiplies of the first version cost ~450 cycles per frame).
     int c0, c1;
-    chunk_run(n_chunks, c0, c1);
+    chunk_run(n_chunks, c0, c1, vgrid, vblock);
     // AA_V_ILV: interleaved chunks instead of one contiguous run per workgroup - at any time the
     // resident workgroups work inside one window of gridDim.x chunks (8 MB of samples, 17 / 34 MB of
     // rows), XCD x (= blockIdx % 8) on the x-th eighth of it so that neighbouring chunks share an L2:
@@ -1523,12 +1552,20 @@ __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_e
 void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor, const float *__restrict__ mel_par, MelSched sch)
+    float log_floor, const float *__restrict__ mel_par, MelSched sch, int n_streams, int64_t stream_in_stride,
+    int64_t stream_out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, lane0 = lane;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int vgrid, vblock;
+    {
+        int64_t in_off, out_off;
+        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
+        x += in_off;
+        out += out_off;
+    }
     constexpr bool STREAM = RING == 1;               // constants streamed, four workgroups per CU
     constexpr int RB = RING == 2 ? 30 : kRingBlocks;  // ring blocks
     constexpr int DEPTH = RING == 2 ? 2 : 1;         // chunks the DMA runs ahead
@@ -1538,7 +1575,7 @@ void stft_wave2048_kernel(
     }
 
     int c0, c1;
-    chunk_run(n_chunks, c0, c1);
+    chunk_run(n_chunks, c0, c1, vgrid, vblock);
     const int max_span = (frames_per_wg - 1) * hop + 2048;
     const int stage_dwords = RING ? RB * 256 : 2 * max_span;
     v2f *scr = reinterpret_cast<v2f *>(smem + stage_dwords + wave * kWave1024ScratchDwords);
@@ -2732,11 +2769,23 @@ static int persistent_grid(K kernel, size_t lds)
     return cus * per_cu * mult;
 }
 
+// Grid of a launch over ch channels: ch equal groups of workgroups (stream_of_block), together at most
+// the persistent grid of the device.
+static unsigned channel_grid(int64_t persistent, int64_t chunks, int n_channels)
+{
+    int64_t per = persistent / (n_channels > 0 ? n_channels : 1);
+    if (per < 1)
+        per = 1;
+    if (per > chunks)
+        per = chunks;
+    return (unsigned)(per * (n_channels > 0 ? n_channels : 1));
+}
+
 template <int K>
 static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
-                                       const MelSched &sch, const float *dct_tab = nullptr, int n_mfcc = 0)
+                                       const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kMfccR ? 2 : (K == kLogMel || K == kLogMelR) ? 1 : 0);
@@ -2749,24 +2798,29 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
     int64_t want = cached_grid;
     if (const char *e = getenv("AA_GRID_SET"))           // experiments: another number of persistent workgroups
         want = atoi(e) > 0 ? atoi(e) : want;
-    const dim3 grid((unsigned)(want < chunks ? want : chunks)), block(kWave1024Threads);
+    const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
 #ifndef AA_V_ABL
 #define AA_V_ABL 0      // experiments: an ablation / variant mask of stft_wave1024_kernel in the product launcher
 #endif
     if (wide)
         hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
+                           ch.n, ch.in_stride, ch.out_stride);
     else
         hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
+                           ch.n, ch.in_stride, ch.out_stride);
     return hipGetLastError();
 }
 
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched,
-                           const float *dct_tab, int n_mfcc)
+                           const float *dct_tab, int n_mfcc, const Channels *channels)
 {
+    const Channels ch = channels ? *channels : Channels();
+    if (ch.n < 1 || (ch.n > 1 && ((ch.in_stride | ch.out_stride) & 3)))
+        return hipErrorInvalidValue;
     if (n_frames <= 0)
         return hipSuccess;
     const MelSched sch = sched ? *sched : MelSched();
@@ -2781,19 +2835,19 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kMag:
-        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kPower:
-        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kLogPower:
-        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kLogMel:
-        return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kLogMelR:
-        return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kMfccR:
-        return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, dct_tab, n_mfcc);
+        return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, dct_tab, n_mfcc, ch);
     default:
         return hipErrorInvalidValue;
     }
@@ -2803,7 +2857,7 @@ template <int K, int NS = 0>
 static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
-                                       const MelSched &sch)
+                                       const MelSched &sch, const Channels &ch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
     constexpr int kMelKind = K == kLogMelR ? 2 : K == kLogMel ? 1 : 0;
@@ -2833,26 +2887,34 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
                                : persistent_grid(stft_wave2048_kernel<K, true, NS, 0>, lds);
         cached_lds[ri] = lds;
     }
-    const dim3 grid((unsigned)(cached_grid[ri] < chunks ? cached_grid[ri] : chunks)), block(kWave1024Threads);
+    const dim3 grid(channel_grid(cached_grid[ri], chunks, ch.n)), block(kWave1024Threads);
     if (ring && wide)
         hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, kRingKind>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
+                           ch.out_stride);
     else if (ring)
         hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, kRingKind>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
+                           ch.out_stride);
     else if (wide)
         hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, 0>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
+                           ch.out_stride);
     else
         hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, 0>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch);
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
+                           ch.out_stride);
     return hipGetLastError();
 }
 
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
-                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched)
+                           float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched,
+                           const Channels *channels)
 {
+    const Channels ch = channels ? *channels : Channels();
+    if (ch.n < 1 || (ch.n > 1 && ((ch.in_stride | ch.out_stride) & 3)))
+        return hipErrorInvalidValue;
     if (n_frames <= 0)
         return hipSuccess;
     const MelSched sch = sched ? *sched : MelSched();
@@ -2863,21 +2925,21 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kMag:
-        return launch_wave2048_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kPower:
-        return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogPower:
-        return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogMel:
-        return launch_wave2048_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+        return launch_wave2048_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogMelR:   // the instantiation with the fewest steps that holds the schedule
         if (sch.n_steps <= 12)
-            return launch_wave2048_kind<kLogMelR, 12>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+            return launch_wave2048_kind<kLogMelR, 12>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
         if (sch.n_steps <= 14)
-            return launch_wave2048_kind<kLogMelR, 14>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
-        return launch_wave2048_kind<kLogMelR, 16>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch);
+            return launch_wave2048_kind<kLogMelR, 14>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
+        return launch_wave2048_kind<kLogMelR, 16>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     default:
         return hipErrorInvalidValue;
     }

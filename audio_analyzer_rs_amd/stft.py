@@ -129,6 +129,38 @@ class Stft:
         return out
 
 
+    def execute_channels_device(self, samples, out=None, stream=None):
+        """samples: contiguous CUDA float32 [channels, n_samples] (planar, equal-length mono channels:
+        BASELINE configs[2] is two of them).  Returns [channels, frames, cols] (complex64
+        [channels, frames, n_fft/2+1] for output="complex"); every channel's rows are bit-identical to
+        `execute_device` on that channel.  One launch for the wave kernels of n_fft 1024 / 2048 when
+        n_samples and frames * cols are multiples of 4, else channel after channel
+        (aa_stft_execute_channels_device)."""
+        import torch
+
+        if not (samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2
+                and samples.is_contiguous()):
+            raise _lib.AaError(_lib.AA_ERR_ARG, "samples must be a contiguous [channels, n] CUDA float32 tensor")
+        if samples.device.index != self.device_index:
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"samples live on cuda:{samples.device.index} but the "
+                               f"plan was created on cuda:{self.device_index}")
+        ch, n = int(samples.shape[0]), int(samples.shape[1])
+        nf = self.num_frames(n)
+        if out is None:
+            out = torch.empty((ch, nf, self.cols), dtype=torch.float32, device=samples.device)
+        elif not (out.is_cuda and out.device == samples.device and out.dtype == torch.float32
+                  and out.is_contiguous() and tuple(out.shape) == (ch, nf, self.cols)):
+            raise _lib.AaError(_lib.AA_ERR_ARG, f"out must be a contiguous CUDA float32 tensor of shape "
+                               f"{(ch, nf, self.cols)} on {samples.device}")
+        st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
+        if ch and nf:
+            _lib.check(self._lib.aa_stft_execute_channels_device(self._plan, samples.data_ptr(), n, n, ch,
+                                                                 out.data_ptr(), nf * self.cols, st))
+        if self.output == "complex":
+            return torch.view_as_complex(out.view(ch, -1, self.cols // 2, 2))
+        return out
+
+
 def pin(array):
     """Page-lock a numpy array in place (aa_host_register).  With both the samples and the output
     array pinned, `Stft.execute_host` overlaps H2D, kernels and D2H on two streams."""

@@ -162,6 +162,17 @@ const char *aa_stft_kernel_name(const aa_stft_plan *plan);
 int aa_stft_execute_device(aa_stft_plan *plan, const float *samples_dev, int64_t n_samples,
                            int64_t frame_begin, int64_t frame_end, float *out_dev,
                            void *stream);
+/* n_channels equal-length mono channels (planar: channel c is samples_dev[c * channel_stride ..
+ * + n_samples)), every frame of each, rows of channel c from out_dev[c * out_channel_stride]
+ * (floats; out_channel_stride >= aa_stft_num_frames * aa_stft_out_cols).  The reference never runs
+ * a multi-channel STFT (it averages stereo to mono at capture, mod.rs:764, 789-793): this is the
+ * "two independent mono channels" form of BASELINE configs[2].  Row c * frames + t is bit-identical
+ * to what aa_stft_execute_device writes for channel c alone; with the wave kernels of n_fft 1024 /
+ * 2048 and both strides multiples of 4 floats all channels run in ONE launch (the persistent
+ * workgroups are split evenly between them), otherwise channel after channel.  Asynchronous. */
+int aa_stft_execute_channels_device(aa_stft_plan *plan, const float *samples_dev, int64_t n_samples,
+                                    int64_t channel_stride, int32_t n_channels, float *out_dev,
+                                    int64_t out_channel_stride, void *stream);
 /* All frames of a host buffer; synchronous (H2D, kernels, D2H through the
  * plan's workspace).  out_host holds aa_stft_num_frames * aa_stft_out_cols floats. */
 int aa_stft_execute_host(aa_stft_plan *plan, const float *samples_host, int64_t n_samples,

@@ -86,6 +86,7 @@ def test_bad_arguments_return_status_not_abort(lib):
     assert lib.aa_hann_window(0, None) == _lib.AA_ERR_ARG
     cfg = _lib.StftConfig(1024, 0, 0, 1, 48000, 0, 0, 0.0, 0.0, 0.0)
     assert lib.aa_stft_plan_create(ctypes.byref(cfg), None, ctypes.byref(plan)) == _lib.AA_ERR_ARG
+    assert lib.aa_stft_execute_channels_device(None, None, 4096, 4096, 2, None, 0, None) == _lib.AA_ERR_ARG
     assert lib.aa_fft_destroy(None) == 0 and lib.aa_stft_plan_destroy(None) == 0
 
 

@@ -421,6 +421,33 @@ def test_mel_argument_errors(aa):
         aa.Stft(1024, 256, output="mfcc", n_mels=40, n_mfcc=41)
 
 
+@pytest.mark.parametrize("n,hop,output,kw", [
+    (2048, 512, "logmel", dict(sample_rate=48000, n_mels=128)),      # BASELINE configs[2]: stereo log-mel
+    (2048, 512, "mag", {}), (2048, 512, "complex", {}), (1024, 256, "mag", {}), (1024, 256, "complex", {}),
+    (1024, 256, "mfcc", dict(sample_rate=48000, n_mels=128, n_mfcc=40)),
+    (1024, 256, "logmel", dict(sample_rate=48000, n_mels=80)), (2048, 500, "power", {}),
+    (256, 64, "mag", {}), (4096, 1024, "mag", {}), (2048, 512, "mfcc", dict(sample_rate=48000, n_mels=128, n_mfcc=40))])
+@pytest.mark.parametrize("channels,n_frames", [(2, 12290), (3, 37), (2, 4), (5, 1001)])
+def test_channels_in_one_launch_equal_single_channel_launches(aa, torch_mod, n, hop, output, kw, channels, n_frames):
+    """aa_stft_execute_channels_device: planar mono channels, one launch where the plan is a single
+    wave kernel (the persistent workgroups split evenly between the channels), channel after channel
+    elsewhere (256, 4096, unfused MFCC, strides that are not multiples of 4 floats).  Either way
+    every channel's rows are bit-identical to a launch of that channel alone."""
+    L = n + (n_frames - 1) * hop
+    xs = np.stack([aa.signals.synth_corpus(100 * c, L, seed=12345 + 7 * c) for c in range(channels)])
+    xd = torch_mod.from_numpy(xs).cuda()
+    plan = aa.Stft(n, hop, output=output, **kw)
+    got = plan.execute_channels_device(xd)
+    assert got.shape[:2] == (channels, n_frames)
+    for c in range(channels):
+        alone = plan.execute_device(xd[c].clone())
+        assert torch_mod.equal(got[c], alone), c
+    # a preallocated output, a second call (buffers reused)
+    out = torch_mod.empty((channels, n_frames, plan.cols), dtype=torch_mod.float32, device="cuda")
+    again = plan.execute_channels_device(xd, out=out)
+    assert torch_mod.equal(again, got)
+
+
 def test_downmix_matches_capture_rule(aa, torch_mod):
     g = torch_mod.Generator(device="cuda").manual_seed(3)
     for ch in (1, 2, 3, 6):
