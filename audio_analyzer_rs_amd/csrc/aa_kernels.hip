@@ -1464,10 +1464,11 @@ void stft_wave1024_kernel(
 //   Z[k] = E[k] + W_1024^k O[k],  Z[k+512] = E[k] - W_1024^k O[k]          (in-lane)
 //   X[k], X[1024-k] from Z[k], conj(Z[1024-k]) with -i W_2048^k; the upper half of Z crosses
 //   the wave-private LDS strip (8 ds_write_b64 + 8 ds_read_b64 per lane)
-// Staging (LDS-DMA double buffer), persistence, row staging and store scheme as in
-// stft_wave1024_kernel.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
+// Persistence, row staging and store scheme as in stft_wave1024_kernel; staging by LDS-DMA: the two
+// chunk buffers of that kernel for any hop, a ring with the DMA two chunks ahead (RING == 2, below)
+// for the tuner geometry itself.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
 // 32..45 W_512^(lane k), 46..59 W_64^((lane>>3) k), 60..75 W_1024^(lane+64kb),
-// 76..91 -i W_2048^(lane+64kb).
+// 76..91 -i W_2048^(lane+64kb); behind them the float4 tables of the RING == 1 experiment.
 __device__ __forceinline__ void fft512_pass_a(v2f (&v)[8], const v2f (&twA)[8])
 {
     pk_dft8(v);
@@ -1517,7 +1518,8 @@ __device__ __forceinline__ void vm_wait_tied8(v4f (&w)[8])
                  : "n"(N)
                  : "memory");
 }
-// RING (hop 512, 4 frames per chunk - the tuner geometry): FOUR workgroups per CU instead of three.
+// RING == 1 (hop 512, 4 frames per chunk; an experiment that lost, built with -DAA_RING_COMPLEX=1 only,
+// DESIGN.md section 8): FOUR workgroups per CU instead of three.
 //  * staging: one ring of 22 blocks of 256 floats (22.5 KB) instead of two chunk buffers (28.7 KB): a
 //    chunk is blocks [8 i, 8 i + 14) of the workgroup's sample run, block b lives in slot b mod 22, the
 //    8 new blocks of chunk i + 1 overwrite blocks 8 i - 8 .. 8 i - 1 (dead since the chunk-top barrier);
@@ -1541,8 +1543,9 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_R_TWS
 #define AA_R_TWS 0
 #endif
-// RING == 2: the ring alone, 30 blocks, with the LDS-DMA running TWO chunks ahead (three workgroups per
-// CU, constants resident as in the plain variant).  With four frames per chunk and three workgroups per
+// RING == 2 (shipped for the tuner geometry): the ring alone, 30 blocks (block b of the workgroup's
+// sample run in slot b mod 30), with the LDS-DMA running TWO chunks ahead (three workgroups per CU,
+// constants resident as in the plain variant).  With four frames per chunk and three workgroups per
 // CU a chunk lasts ~1.7 us - about one HBM round trip under load - so the one-chunk-ahead DMA of the
 // plain variant arrives late whenever the samples come from HBM rather than the Infinity Cache; the
 // fused mel variants, whose streamed weights are waited for in mid-frame (vmcnt retires in order: that
