@@ -977,6 +977,25 @@ void stft_wave1024_kernel(
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
     const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
+#ifndef AA_V_MFCC_DEFER
+#define AA_V_MFCC_DEFER 1  // kMfccR: DCT results stored from the top of the next chunk
+#endif
+    v4f pend0 = {0.0f, 0.0f, 0.0f, 0.0f}, pend1 = pend0;   // kMfccR: accumulators of the last DCT block
+    float *pend_row = nullptr;
+    int pend_coef0 = 0;
+    bool pending = false;
+    auto flush_dct = [&]() {
+        if (OUT == kMfccR && AA_V_MFCC_DEFER && pending) {
+            const v4f d = pend0 + pend1;
+            if (pend_row) {
+                if (pend_coef0 + 0 < n_mfcc) pend_row[0] = d.x;
+                if (pend_coef0 + 2 < n_mfcc) pend_row[2] = d.y;
+                if (pend_coef0 + 4 < n_mfcc) pend_row[4] = d.z;
+                if (pend_coef0 + 6 < n_mfcc) pend_row[6] = d.w;
+            }
+            pending = false;
+        }
+    };
     int it = 0;
     for (int c = c0; c < c1; c += cstep, ++it) {
         const int cur = it & 1;
@@ -1001,6 +1020,7 @@ void stft_wave1024_kernel(
             const int nleft = frames_left - frames_step;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
+        flush_dct();
         const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
 
@@ -1417,18 +1437,28 @@ void stft_wave1024_kernel(
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, b3.z, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b2.w, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, b3.w, acc1, 0, 0, 0);
-                const v4f d = acc0 + acc1;
                 // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
                 const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
                 const int have = (it & 1) ? 8 + nf : nf;               // valid rows (a lone last chunk: rows 0..7)
                 // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's
                 float *orow = ((it & 1) ? (j < 8 ? out_chunk - out_stride + j * COLS : out_chunk + (j - 8) * COLS)
                                         : out_chunk + j * COLS) + coef0;
-                if (j < have) {
-                    if (coef0 + 0 < n_mfcc) orow[0] = d.x;
-                    if (coef0 + 2 < n_mfcc) orow[2] = d.y;
-                    if (coef0 + 4 < n_mfcc) orow[4] = d.z;
-                    if (coef0 + 6 < n_mfcc) orow[6] = d.w;
+                if (AA_V_MFCC_DEFER) {
+                    // the 16 MFMAs take ~500 cycles to drain: their results are stored from the top of
+                    // the next chunk (or behind the loop), not waited for here
+                    pend0 = acc0;
+                    pend1 = acc1;
+                    pend_row = j < have ? orow : nullptr;
+                    pend_coef0 = coef0;
+                    pending = true;
+                } else {
+                    const v4f d = acc0 + acc1;
+                    if (j < have) {
+                        if (coef0 + 0 < n_mfcc) orow[0] = d.x;
+                        if (coef0 + 2 < n_mfcc) orow[2] = d.y;
+                        if (coef0 + 4 < n_mfcc) orow[4] = d.z;
+                        if (coef0 + 6 < n_mfcc) orow[6] = d.w;
+                    }
                 }
             }
         } else {
@@ -1452,6 +1482,7 @@ void stft_wave1024_kernel(
         out_chunk += out_stride;
         frames_left -= frames_step;
     }
+    flush_dct();
     AA_CLK_END
 }
 
