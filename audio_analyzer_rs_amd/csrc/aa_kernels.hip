@@ -35,6 +35,12 @@ __device__ unsigned long long aa_clk_dbg[4 * 8192];
 #define AA_CLK_END
 #endif
 
+// AA_SAFE_WAITS=1 (tools/check_counted_waits.sh only): every counted s_waitcnt becomes a full wait.  A
+// library built that way must produce the same bits as the shipped one; a counted wait that let a
+// load or an LDS-DMA piece slip would show as a difference.
+#ifndef AA_SAFE_WAITS
+#define AA_SAFE_WAITS 0
+#endif
 // ------------------------------------------------------------------ helpers --
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -68,7 +74,7 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt_le()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AA_SAFE_WAITS ? 0 : N) : "memory");
 }
 // Row stores: nontemporal (the rows are written once and not read by this kernel).  AA_V_STORE = 1
 // (experiments): plain stores.
@@ -371,7 +377,7 @@ template <int KEEP>   // wait until at most KEEP newer LDS operations are outsta
 __device__ __forceinline__ void mel_lds_wait(v2f &a, v2f &b)
 {
     if (KEEP == 2)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(AA_SAFE_WAITS ? 0 : 2) : "memory");
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
 }
@@ -513,9 +519,9 @@ template <int KEEP, int F>   // wait until at most KEEP newer LDS operations are
 __device__ __forceinline__ void mel_lds_wait_step(v2f (&c)[4])
 {
     if (F == 2)
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(KEEP) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(AA_SAFE_WAITS ? 0 : KEEP) : "memory");
     else
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(KEEP) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : KEEP) : "memory");
 }
 template <int NS, int F>
 __device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident<NS> &mr,
@@ -676,17 +682,17 @@ __device__ __forceinline__ void mel_reduce_streamed(unsigned rows_addr, const fl
         constexpr int kMax = (DL - 1) * 2;
         const int newer = (NS - 1 - s) * 2;          // LDS loads issued after this step's
         if (newer >= kMax)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(kMax) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : kMax) : "memory");
         else if (newer == 10)
-            asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(c[0]), "+v"(c[1])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 10) : "memory");
         else if (newer == 8)
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(c[0]), "+v"(c[1])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 8) : "memory");
         else if (newer == 6)
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c[0]), "+v"(c[1])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 6) : "memory");
         else if (newer == 4)
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(c[0]), "+v"(c[1])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 4) : "memory");
         else if (newer == 2)
-            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(c[0]), "+v"(c[1])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 2) : "memory");
         else
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1])::"memory");
         const v2f w01 = {W[s].x, W[s].y}, w23 = {W[s].z, W[s].w};
@@ -1546,7 +1552,7 @@ __device__ __forceinline__ void vm_wait_tied8(v4f (&w)[8])
 {
     asm volatile("s_waitcnt vmcnt(%8)"
                  : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
-                 : "n"(N)
+                 : "n"(AA_SAFE_WAITS ? 0 : N)
                  : "memory");
 }
 // RING == 1 (hop 512, 4 frames per chunk; an experiment that lost, built with -DAA_RING_COMPLEX=1 only,
