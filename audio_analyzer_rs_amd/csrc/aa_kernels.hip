@@ -2905,7 +2905,7 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
     // chunks ahead (RING == 2): log-mel 96.4 -> 88.2 us, magnitudes 82.9 -> 80.1, complex rows 96.3 ->
     // 91.7 with the samples coming from HBM (two inputs alternating).  The four-workgroup variant with
     // streamed constants (RING == 1) loses to it everywhere (complex rows 96.4-100.5 us, magnitudes
-    // +3-6 %: the constants occupy the L1 path) and is only built with -DAA_RING_COMPLEX=1.  The mel
+    // +3-6 %: the extra residents only queue for issue slots) and is only built with -DAA_RING_COMPLEX=1.  The mel
     // variant with arithmetic weights keeps the two chunk buffers (its LDS has no room for the ring).
     // AA_W2048_RING=0: experiments.
 #ifndef AA_RING_COMPLEX

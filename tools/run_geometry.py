@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import audio_analyzer_rs_amd as aa
+if os.environ.get("AA_TOOL_LIB"):                    # another build of the library (experiments)
+    aa._lib.LIB_PATH = os.path.abspath(os.environ["AA_TOOL_LIB"])
 n, hop, outk, reps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 alt = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 kw = dict(n_mels=128) if outk in ("logmel", "mfcc") else {}
