@@ -14,6 +14,8 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,6 +66,7 @@ void load_rccl()
         {"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL, "/opt/rocm/lib/librccl.so.1"},
     };
     void *h = nullptr;
+    char why[160] = "";            // message of the first real load that failed (RTLD_NOLOAD probes do not count)
     for (const Cand &c : cands) {
         if (!c.path || !*c.path)
             continue;
@@ -72,9 +75,12 @@ void load_rccl()
             g_rccl.origin = c.origin;
             break;
         }
+        const char *msg = dlerror();                         // once: the call clears the error
+        if (!(c.flags & RTLD_NOLOAD) && !why[0])
+            snprintf(why, sizeof why, "%s: %s", c.origin, msg ? msg : "dlopen failed");
     }
     if (!h) {
-        snprintf(g_rccl_error, sizeof g_rccl_error, "librccl not found (%s)", dlerror() ? dlerror() : "dlopen");
+        snprintf(g_rccl_error, sizeof g_rccl_error, "librccl not found (%s)", why[0] ? why : "no candidate path");
         return;
     }
     bool ok = true;
@@ -137,6 +143,28 @@ struct GroupScope {
             (void)g_rccl.GroupEnd();
     }
 };
+
+// The communicator's device is selected for the duration of every call that takes a comm: a host
+// thread that never called hipSetDevice sits on device 0, and hipMemcpyAsync / hipStreamSynchronize /
+// ncclSend / ncclRecv act on the CURRENT device (as the plan entry points do in aa_abi.cpp).
+struct CommDeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit CommDeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
+            ok = true;
+    }
+    ~CommDeviceGuard()
+    {
+        if (ok && prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+#define COMM_DEVICE(c, what)                                                                   \
+    CommDeviceGuard dev_guard_((c)->device);                                                   \
+    if (!dev_guard_.ok)                                                                        \
+    return fail(AA_ERR_HIP, what ": cannot select device %d", (c)->device)
 
 void frames_of(int64_t total, int world, int r, int64_t *f0, int64_t *f1)
 {
@@ -216,6 +244,7 @@ int aa_comm_destroy(aa_comm *c)
     if (!c)
         return AA_OK;
     int rc = AA_OK;
+    CommDeviceGuard g(c->device);                            // best effort: the handle is released either way
     if (c->comm && g_rccl.CommDestroy) {
         ncclResult_t r = g_rccl.CommDestroy(c->comm);
         if (r != 0)
@@ -233,6 +262,7 @@ int aa_comm_barrier(aa_comm *c, void *stream)
 {
     if (!c)
         return fail(AA_ERR_ARG, "aa_comm_barrier: NULL comm");
+    COMM_DEVICE(c, "aa_comm_barrier");
     hipStream_t st = static_cast<hipStream_t>(stream);
     GroupScope grp;
     NCCL_TRY(grp.begin());
@@ -254,6 +284,7 @@ int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int
         return fail(AA_ERR_ARG, "aa_scatter_samples: bad argument");
     if (c->rank == root && !full_dev && n_samples > 0)
         return fail(AA_ERR_ARG, "aa_scatter_samples: the root needs the whole buffer");
+    COMM_DEVICE(c, "aa_scatter_samples");
     const int64_t total = n_samples < n_fft ? 0 : (n_samples - n_fft) / hop + 1;
     int64_t f0, f1, s0, s1;
     frames_of(total, c->world, c->rank, &f0, &f1);
@@ -292,6 +323,7 @@ int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int3
 {
     if (!c || total_frames < 0 || cols <= 0 || root < -1 || root >= c->world)
         return fail(AA_ERR_ARG, "aa_gather_rows: bad argument");
+    COMM_DEVICE(c, "aa_gather_rows");
     int64_t f0, f1;
     frames_of(total_frames, c->world, c->rank, &f0, &f1);
     const bool receiver = root < 0 || root == c->rank;

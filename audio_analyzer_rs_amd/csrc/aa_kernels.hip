@@ -2789,6 +2789,29 @@ __global__ void irfft_kernel(const float *__restrict__ spec, float *__restrict__
 #ifndef AA_ABLATE   // the diagnostic build (tools/ablate_w1024.hip) drives the kernel itself
 // Persistent grid: resident workgroups per CU (occupancy API) x CUs.  There is no
 // inter-workgroup dependency, so an over- or under-estimate only changes speed.
+// Experiment knobs of the launchers (AA_GRID_MULT, AA_GRID_SET, AA_W2048_RING, AA_LDS_PAD) exist only in
+// libraries built with -DAA_EXPERIMENTS=1 (tools/probe_bimodal_grid.py, tools/profile_ring.sh): the shipped
+// library never reads the process environment on a launch.  Values outside [lo, hi] are ignored.
+#ifndef AA_EXPERIMENTS
+#define AA_EXPERIMENTS 0
+#endif
+static int experiment_knob(const char *name, int dflt, int lo, int hi)
+{
+#if AA_EXPERIMENTS
+    if (const char *e = getenv(name)) {
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && *end == '\0' && v >= lo && v <= hi)
+            return (int)v;
+    }
+#else
+    (void)name;
+    (void)lo;
+    (void)hi;
+#endif
+    return dflt;
+}
+
 template <typename K>
 static int persistent_grid(K kernel, size_t lds)
 {
@@ -2801,12 +2824,9 @@ static int persistent_grid(K kernel, size_t lds)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave1024Threads, lds) != hipSuccess ||
         per_cu < 1)
         per_cu = 1;
-    // AA_GRID_MULT (experiments): that many dispatch generations per resident slot instead of one
+    // AA_GRID_MULT (experiment builds): that many dispatch generations per resident slot instead of one
     // persistent workgroup (the hardware dispatcher then balances the tail)
-    int mult = 1;
-    if (const char *e = getenv("AA_GRID_MULT"))
-        mult = atoi(e) > 0 ? atoi(e) : 1;
-    return cus * per_cu * mult;
+    return cus * per_cu * experiment_knob("AA_GRID_MULT", 1, 1, 16);
 }
 
 // Grid of a launch over ch channels: ch equal groups of workgroups (stream_of_block), together at most
@@ -2835,9 +2855,8 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
         cached_grid = persistent_grid(stft_wave1024_kernel<K, 0, true>, lds);
         cached_lds = lds;
     }
-    int64_t want = cached_grid;
-    if (const char *e = getenv("AA_GRID_SET"))           // experiments: another number of persistent workgroups
-        want = atoi(e) > 0 ? atoi(e) : want;
+    // AA_GRID_SET (experiment builds): another number of persistent workgroups
+    const int64_t want = experiment_knob("AA_GRID_SET", cached_grid, 1, 1 << 16);
     const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
 #ifndef AA_V_ABL
 #define AA_V_ABL 0      // experiments: an ablation / variant mask of stft_wave1024_kernel in the product launcher
@@ -2913,12 +2932,14 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
 #endif
     constexpr int kRingKind = K == kComplex ? AA_RING_COMPLEX : K == kLogMel ? 0 : 2;   // built for this output kind
     int ring = hop == 512 && frames_per_wg == 4 ? kRingKind : 0;
-    if (const char *e = getenv("AA_W2048_RING"))
-        ring = atoi(e) != 0 ? ring : 0;
+    if (experiment_knob("AA_W2048_RING", 1, 0, 1) == 0)     // experiment builds: the two chunk buffers
+        ring = 0;
     size_t lds = ring ? wave2048_ring_lds_bytes(ring == 2 ? 30 : 22, kMelKind)
                       : wave2048_lds_bytes(frames_per_wg, hop, kMelKind != 0);
-    if (const char *e = getenv("AA_LDS_PAD"))           // experiments: fewer resident workgroups per CU
-        lds += (size_t)atoi(e);
+    // AA_LDS_PAD (experiment builds): fewer resident workgroups per CU; never past the 64 KiB a plan validated
+    const size_t pad = (size_t)experiment_knob("AA_LDS_PAD", 0, 0, 65536);
+    if (lds + pad <= 65536)
+        lds += pad;
     const int ri = ring ? 1 : 0;
     static thread_local int cached_grid[2] = {0, 0};   // per thread: plans of different threads are independent
     static thread_local size_t cached_lds[2] = {0, 0};

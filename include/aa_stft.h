@@ -396,7 +396,16 @@ int aa_shard_samples(int64_t f0, int64_t f1, int32_t n_fft, int32_t hop, int64_t
  * Bootstrap as with NCCL: rank 0 calls aa_comm_unique_id and hands the 128 bytes to the other
  * ranks by any means it has (a file, a pipe, MPI, the launcher's store); then EVERY rank calls
  * aa_comm_create with the same id, its rank and the world size, after selecting its GPU
- * (hipSetDevice) — the communicator binds to the current device. */
+ * (hipSetDevice) — the communicator binds to the current device, and every later call that takes
+ * the communicator selects that device for its own duration (AA_ERR_HIP if it cannot), so it may
+ * come from any host thread.
+ *
+ * Verification status: at world size 1 these run on the real librccl on one MI355X
+ * (tests/test_comm_gpu.py).  For worlds of 2, 3 and 8 ranks the send / receive lists every rank
+ * issues — peers, offsets, counts, groups, the all-gather form, totals below the world size — are
+ * pinned against aa_shard_frames / aa_shard_samples with a loopback stand-in for librccl
+ * (tests/test_comm_stub.py); RCCL itself moving those bytes between GPUs has not run yet (no
+ * multi-GPU node was available): multi-rank transport is UNVERIFIED on hardware. */
 #define AA_COMM_ID_BYTES 128
 typedef struct aa_comm_id {
     char bytes[AA_COMM_ID_BYTES];

@@ -1,0 +1,253 @@
+"""Multi-rank call lists of the C-ABI collectives (csrc/aa_comm.cpp: aa_scatter_samples, aa_gather_rows,
+aa_comm_barrier) for worlds of 2, 3 and 8 ranks, without a second GPU: a loopback stand-in for librccl
+(tests/stubs/rccl_loopback.c, bound through AA_RCCL_PATH) keeps every rank of a world in ONE process, logs
+each ncclSend / ncclRecv (rank, peer, pointer, count, group, current device) and carries matched pairs out.
+Checked from every rank, for roots at both ends and the all-gather form, for frame totals below the world
+size and for an empty job: sends and receives pair up, their offsets and counts are those of
+aa_shard_frames / aa_shard_samples, the bytes arrive, no group is left open on an error path and the
+communicator's device is selected around every call.
+
+CPU leg (`-m "not gpu"`): the few HIP calls of aa_comm.cpp are answered from host memory by
+tests/stubs/hip_host.c (LD_PRELOAD in a child process that does not import torch).  GPU leg (`-m gpu`): the
+same child on the real HIP runtime with device buffers.  What this cannot show is RCCL itself moving the
+bytes between two GPUs: that needs the driver's multi-GPU node."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUBS = os.path.join(ROOT, "tests", "stubs")
+
+CHILD = r'''
+import ctypes, os, sys
+import numpy as np
+
+ROOT, RCCL_STUB, HOST_HIP = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+assert "torch" not in sys.modules
+if not HOST_HIP:
+    ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+hip = ctypes.CDLL(None)                     # global scope: the preloaded stand-in first, else the real runtime
+lib = ctypes.CDLL(os.path.join(ROOT, "audio_analyzer_rs_amd", "libaa_stft.so"))
+stub = ctypes.CDLL(RCCL_STUB)               # same handle the library dlopens (one copy per path)
+vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+hip.hipMalloc.argtypes = [ctypes.POINTER(vp), sz]
+hip.hipMemcpy.argtypes = [vp, vp, sz, ctypes.c_int]
+hip.hipFree.argtypes = [vp]
+hip.hipSetDevice.argtypes = [ctypes.c_int]
+lib.aa_last_error.restype = ctypes.c_char_p
+lib.aa_comm_backend.restype = ctypes.c_char_p
+lib.aa_comm_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+lib.aa_comm_destroy.argtypes = [vp]
+lib.aa_comm_barrier.argtypes = [vp, vp]
+lib.aa_scatter_samples.argtypes = [vp, vp, i64, i32, i32, i32, vp, i64, vp]
+lib.aa_gather_rows.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+lib.aa_shard_frames.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+lib.aa_shard_samples.argtypes = [i64, i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+stub.aa_stub_log_get.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 5 + [ctypes.POINTER(ctypes.c_size_t)] * 2
+
+
+def ok(rc):
+    assert rc == 0, (rc, lib.aa_last_error())
+
+
+class Dev:
+    """n floats of `device` memory (host memory under the stand-in)."""
+    def __init__(self, n, fill=None):
+        self.n = n
+        p = vp()
+        assert hip.hipMalloc(ctypes.byref(p), max(4 * n, 4)) == 0
+        self.ptr = p.value
+        if fill is not None:
+            self.put(np.ascontiguousarray(fill, dtype=np.float32))
+        else:
+            self.put(np.full(n, np.nan, dtype=np.float32))
+    def put(self, a):
+        assert a.size == self.n
+        if self.n:
+            assert hip.hipMemcpy(self.ptr, a.ctypes.data, 4 * self.n, 1) == 0
+    def get(self):
+        a = np.empty(self.n, dtype=np.float32)
+        if self.n:
+            assert hip.hipMemcpy(a.ctypes.data, self.ptr, 4 * self.n, 2) == 0
+        return a
+    def free(self):
+        hip.hipFree(self.ptr)
+
+
+def shard_frames(total, world, r):
+    f0, f1 = i64(), i64()
+    ok(lib.aa_shard_frames(total, world, r, ctypes.byref(f0), ctypes.byref(f1)))
+    return f0.value, f1.value
+
+
+def shard_samples(f0, f1, n, hop):
+    s0, s1 = i64(), i64()
+    ok(lib.aa_shard_samples(f0, f1, n, hop, ctypes.byref(s0), ctypes.byref(s1)))
+    return s0.value, s1.value
+
+
+def log():
+    out = []
+    for i in range(stub.aa_stub_log_count()):
+        v = [ctypes.c_int() for _ in range(5)]
+        p, c = ctypes.c_size_t(), ctypes.c_size_t()
+        assert stub.aa_stub_log_get(i, *[ctypes.byref(x) for x in v], ctypes.byref(p), ctypes.byref(c)) == 0
+        out.append(dict(op="send" if v[0].value == 0 else "recv", rank=v[1].value, peer=v[2].value,
+                        in_group=v[3].value, device=v[4].value, ptr=p.value, count=c.value))
+    return out
+
+
+def quiet():
+    assert stub.aa_stub_errors() == 0 and stub.aa_stub_pending() == 0 and stub.aa_stub_group_depth() == 0
+    a, b = ctypes.c_int(), ctypes.c_int()
+    stub.aa_stub_group_calls(ctypes.byref(a), ctypes.byref(b))
+    assert a.value == b.value, "ncclGroupStart / ncclGroupEnd calls differ"
+
+
+def pairs_up(entries):
+    """every send (r -> p, count) has its receive (p <- r, count), in order per pair of ranks"""
+    sends, recvs = {}, {}
+    for e in entries:
+        key = (e["rank"], e["peer"]) if e["op"] == "send" else (e["peer"], e["rank"])
+        (sends if e["op"] == "send" else recvs).setdefault(key, []).append(e["count"])
+    assert sends == recvs, (sends, recvs)
+
+
+assert b"AA_RCCL_PATH" in lib.aa_comm_backend(), lib.aa_comm_backend()
+uid = (ctypes.c_char * 128)()
+ok(lib.aa_comm_unique_id(uid))
+N, HOP = 1024, 256
+checked = 0
+for world in (2, 3, 8):
+    comms = []
+    for r in range(world):
+        if HOST_HIP:
+            assert hip.hipSetDevice(r) == 0          # rank r's GPU is current when its communicator is made
+        c = vp()
+        ok(lib.aa_comm_create(uid, world, r, ctypes.byref(c)))
+        comms.append(c)
+    if HOST_HIP:
+        assert hip.hipSetDevice(0) == 0              # ... and is NOT current any more when it is used
+    dev_of = (lambda r: r) if HOST_HIP else (lambda r: 0)
+
+    # ---- barrier: world sends + world receives per rank, one group each ----
+    stub.aa_stub_reset()
+    for r in range(world):
+        ok(lib.aa_comm_barrier(comms[r], None))
+    L = log()
+    quiet(); pairs_up(L)
+    assert len(L) == 2 * world * world and all(e["in_group"] and e["count"] == 1 for e in L)
+    assert all(e["device"] == dev_of(e["rank"]) for e in L)
+
+    for total_frames in (1000 + 37 * world + 5, world - 1, 1, 0):
+        n_samples = 0 if total_frames == 0 else N + (total_frames - 1) * HOP + 17     # a ragged tail too
+        x = np.random.default_rng(world * 1000 + total_frames).standard_normal(n_samples).astype(np.float32)
+        ranges = [shard_samples(*shard_frames(total_frames, world, r), N, HOP) for r in range(world)]
+        assert sum(f1 - f0 for f0, f1 in (shard_frames(total_frames, world, r) for r in range(world))) == total_frames
+        for root in (0, world - 1):
+            # ---- scatter ----
+            stub.aa_stub_reset()
+            full = Dev(n_samples, x)
+            local = [Dev(s1 - s0 + 3) for s0, s1 in ranges]
+            for r in range(world):                                   # root first or root last: both orders
+                ok(lib.aa_scatter_samples(comms[r], full.ptr if r == root else None, n_samples, N, HOP, root,
+                                          local[r].ptr, local[r].n, None))
+            L = log()
+            quiet(); pairs_up(L)
+            for r, (s0, s1) in enumerate(ranges):
+                got = local[r].get()
+                assert np.array_equal(got[:s1 - s0], x[s0:s1]) and np.isnan(got[s1 - s0:]).all(), (world, root, r)
+            sends = [e for e in L if e["op"] == "send"]
+            want = {r: ranges[r] for r in range(world) if r != root and ranges[r][1] > ranges[r][0]}
+            assert {e["peer"]: ((e["ptr"] - full.ptr) // 4, (e["ptr"] - full.ptr) // 4 + e["count"]) for e in sends} == want
+            assert all(e["rank"] == root and e["in_group"] and e["device"] == dev_of(root) for e in sends)
+            recvs = [e for e in L if e["op"] == "recv"]
+            assert {e["rank"]: (e["ptr"], e["count"]) for e in recvs} == \
+                {r: (local[r].ptr, s1 - s0) for r, (s0, s1) in want.items()}
+            assert all(e["peer"] == root and e["device"] == dev_of(e["rank"]) for e in recvs)
+            # a local buffer one sample short is refused before anything is posted
+            if ranges[root ^ 1 if world == 2 else (root + 1) % world][1] > 0:
+                r = (root + 1) % world
+                stub.aa_stub_reset()
+                rc = lib.aa_scatter_samples(comms[r], None, n_samples, N, HOP, root, local[r].ptr,
+                                            ranges[r][1] - ranges[r][0] - 1, None)
+                assert rc == -2 and stub.aa_stub_log_count() == 0, rc        # AA_ERR_LEN
+            for b in local + [full]:
+                b.free()
+            checked += 1
+        for cols in (5, 513):
+            rows_np = [np.arange(f0 * cols, f1 * cols, dtype=np.float32) for f0, f1 in
+                       (shard_frames(total_frames, world, r) for r in range(world))]
+            for root in (0, world - 1, -1):
+                # ---- gather (root = -1: every rank receives every block) ----
+                stub.aa_stub_reset()
+                rows = [Dev(a.size, a) for a in rows_np]
+                outs = [Dev(total_frames * cols) if root in (-1, r) else None for r in range(world)]
+                for r in range(world):
+                    ok(lib.aa_gather_rows(comms[r], rows[r].ptr if rows[r].n else None, total_frames, cols, root,
+                                          outs[r].ptr if outs[r] and outs[r].n else None, None))
+                L = log()
+                quiet(); pairs_up(L)
+                expect = np.arange(total_frames * cols, dtype=np.float32)
+                for r in range(world):
+                    if outs[r] is not None:
+                        assert np.array_equal(outs[r].get(), expect), (world, root, r, cols)
+                for e in L:
+                    assert e["in_group"] and e["device"] == dev_of(e["rank"])
+                    f0, f1 = shard_frames(total_frames, world, e["rank"] if e["op"] == "send" else e["peer"])
+                    assert e["count"] == (f1 - f0) * cols and e["count"] > 0
+                    if e["op"] == "send":
+                        assert e["ptr"] == rows[e["rank"]].ptr and (root < 0 or e["peer"] == root)
+                    else:
+                        assert e["ptr"] == outs[e["rank"]].ptr + 4 * f0 * cols
+                nonempty = [r for r in range(world) if rows_np[r].size]
+                receivers = list(range(world)) if root < 0 else [root]
+                assert len([e for e in L if e["op"] == "send"]) == sum(1 for s in nonempty for d in receivers if s != d)
+                # error path: rows missing on a rank that owns frames -> AA_ERR_ARG, no group left open
+                if nonempty:
+                    stub.aa_stub_reset()
+                    assert lib.aa_gather_rows(comms[nonempty[0]], None, total_frames, cols, root, None, None) == -1
+                    assert stub.aa_stub_group_depth() == 0 and stub.aa_stub_log_count() == 0
+                for b in rows + [o for o in outs if o is not None]:
+                    b.free()
+                checked += 1
+    if HOST_HIP:
+        h = ctypes.CDLL(None)
+        assert h.aa_hip_host_current_device() == 0, "a collective left another device selected"
+    for c in comms:
+        ok(lib.aa_comm_destroy(c))
+print("scenarios", checked)
+'''
+
+
+def build_stub(name, tmp, extra=()):
+    so = os.path.join(tmp, name + ".so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-Wall", "-o", so, os.path.join(STUBS, name + ".c"), "-ldl",
+                           *extra])
+    return so
+
+
+def run_child(tmp_path, host_hip):
+    so = os.path.join(ROOT, "audio_analyzer_rs_amd", "libaa_stft.so")
+    assert os.path.exists(so), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    rccl = build_stub("rccl_loopback", str(tmp_path))
+    env = dict(os.environ, AA_RCCL_PATH=rccl)
+    if host_hip:
+        env["LD_PRELOAD"] = build_stub("hip_host", str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, rccl, "1" if host_hip else "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "scenarios" in r.stdout
+    return int(r.stdout.split()[-1])
+
+
+def test_comm_call_lists_worlds_2_3_8_host(tmp_path):
+    assert run_child(tmp_path, host_hip=True) == 3 * 4 * (2 + 2 * 3)
+
+
+@pytest.mark.gpu
+def test_comm_call_lists_worlds_2_3_8_device_buffers(tmp_path):
+    assert run_child(tmp_path, host_hip=False) == 3 * 4 * (2 + 2 * 3)

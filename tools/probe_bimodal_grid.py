@@ -1,6 +1,7 @@
 """Probe (diagnostic): launch time of the 1024/256 kernel against the number of persistent workgroups
 (AA_GRID_SET), in one process - i.e. against the byte stride between the workgroups' write streams.
-Run on a GPU box: python tools/probe_bimodal_grid.py [kind]"""
+Run on a GPU box against a library built with -DAA_EXPERIMENTS=1 (the shipped one ignores the knob):
+python tools/probe_bimodal_grid.py [kind]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): wave-state counters of the 2048 kernels with the two chunk buffers
-# (AA_W2048_RING=0) and with the ring two chunks ahead, two inputs alternating (samples from HBM).
+# (library built with -DAA_EXPERIMENTS=1; AA_W2048_RING=0) and with the ring two chunks ahead, two inputs alternating (samples from HBM).
 # Output: gpurun_out/r02_profiles/r02_ring_wait_counters.txt
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof/ring
