@@ -148,6 +148,44 @@ void build_wave1024_table(const float *window, std::vector<float> *tab)
     }
 }
 
+// Per-lane constants of the two-frames-per-wave 1024 kernel (stft_wave1024x2_kernel), [kWave1024x2Rows][64];
+// l = lane & 31 (lane inside its frame), h = (lane >> 4) & 1, kappa = lane & 15, f = lane >> 5:
+//   rows  0..31  0.5 * w[2*(32 j + l) + c]                 (row 2j + c; pass A reads complex point 32 j + l)
+//   rows 32..61  W_512^(l k)  re,im   k = 1..15             (pass A twiddles)
+//   rows 62..77  W_32^(2 p + h)  re,im   p = 0..7           (radix-2 across the lane pair)
+//   rows 78..93  (-sin t, -cos t), t = 2 pi (l + 32 r)/1024, r = 0..7   (= -i W_1024^k, split)
+//   row  94      int bits: complex index of the lane's 16 values in the exchange image,
+//                f F + h P + 18 sigma(kappa)
+void build_wave1024x2_table(const float *window, std::vector<float> *tab)
+{
+    static const int sigma[16] = {2, 11, 6, 15, 0, 9, 4, 13, 8, 1, 12, 5, 10, 3, 14, 7};
+    tab->assign((size_t)aa::kWave1024x2Rows * 64, 0.0f);
+    float *T = tab->data();
+    for (int lane = 0; lane < 64; ++lane) {
+        const int l = lane & 31, h = (lane >> 4) & 1, kappa = lane & 15, f = lane >> 5;
+        for (int j = 0; j < 16; ++j)
+            for (int c = 0; c < 2; ++c)
+                T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (32 * j + l) + c];
+        for (int k = 1; k < 16; ++k) {
+            const double a = -2.0 * kPi * (double)(l * k) / 512.0;
+            T[(32 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
+            T[(33 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
+        }
+        for (int p = 0; p < 8; ++p) {
+            const double a = -2.0 * kPi * (double)(2 * p + h) / 32.0;
+            T[(62 + 2 * p) * 64 + lane] = (float)std::cos(a);
+            T[(63 + 2 * p) * 64 + lane] = (float)std::sin(a);
+        }
+        for (int r = 0; r < 8; ++r) {
+            const double th = 2.0 * kPi * (double)(l + 32 * r) / 1024.0;
+            T[(78 + 2 * r) * 64 + lane] = (float)(-std::sin(th));
+            T[(79 + 2 * r) * 64 + lane] = (float)(-std::cos(th));
+        }
+        const int32_t off = f * aa::kX2FrameStride + h * aa::kX2ParityStride + 18 * sigma[kappa];
+        std::memcpy(&T[94 * 64 + lane], &off, sizeof off);
+    }
+}
+
 constexpr int64_t kMfccSlab = 262144; // frames per log-mel slab of the fused MFCC path
 constexpr int64_t kMelSlab = 32768;  // frames per power-spectrogram slab (<= 134 MB: Infinity-Cache resident; 256 GEMM workgroups)
 
@@ -572,6 +610,8 @@ struct aa_stft_plan {
     bool wave128 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
+    float *d_w1024x2_tab = nullptr;    // stft_wave1024x2_kernel (n_fft 1024 at hop 256, magnitude-type rows)
+    bool wave1024x2 = false;
     // mel / MFCC post-ops (build-defined)
     int n_mels = 0, n_mels_pad = 0, n_mfcc = 0;
     float *d_melT = nullptr;       // [n_bins_pad x n_mels_pad]
@@ -951,6 +991,17 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->frames_per_wg = fpw;
                 p->wave1024 = true;
             }
+            // hop 256 (the BASELINE geometry): magnitude-type rows run on the two-frames-per-wave kernel;
+            // AA_W1024_X2=0 at plan creation keeps the 8 x 8 x 8 kernel for them (A/B runs)
+            const char *x2 = std::getenv("AA_W1024_X2");
+            if (p->wave1024 && cfg->hop == 256 && !(x2 && std::atoi(x2) == 0)) {
+                std::vector<float> tab;
+                build_wave1024x2_table(p->window_host.data(), &tab);
+                AA_HIP(hipMalloc(&p->d_w1024x2_tab, tab.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_w1024x2_tab, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+                p->wave1024x2 = true;
+            }
         }
         // Fused mel reduction in the wave kernels (the power rows never leave the CU); the slab +
         // MFMA GEMM path stays for the generic kernels, unaligned input and AA_MEL_GEMM=1.
@@ -1033,7 +1084,7 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
             (void)hipStreamDestroy(st);
     if (p->pipe_event)
         (void)hipEventDestroy(p->pipe_event);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_dct_lane,
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_w1024x2_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_dct_lane,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
@@ -1056,6 +1107,9 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
 {
     if (!p)
         return "";
+    if (p->wave1024x2 && (p->cfg.output == AA_OUT_MAG || p->cfg.output == AA_OUT_POWER ||
+                          p->cfg.output == AA_OUT_LOGPOWER))
+        return "wave1024x2";
     if (p->wave1024)
         return "wave1024";
     if (p->wave2048)
@@ -1149,7 +1203,10 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
     // The FFT stage: frames [fb, fb+n) -> rows of `dst` in output kind `kind`.
     auto fft_stage = [&](int kind, int64_t fb, int64_t n, float *dst) -> int {
         const float *first = samples_dev + fb * (int64_t)p->cfg.hop;
-        if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+        if (p->wave1024x2 && (kind == aa::kMag || kind == aa::kPower || kind == aa::kLogPower) &&
+            ((reinterpret_cast<uintptr_t>(samples_dev) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+            AA_HIP(aa::launch_wave1024x2(kind, samples_dev, dst, p->d_w1024x2_tab, fb, n, p->log_floor, st, chn));
+        } else if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st, nullptr, nullptr, nullptr, 0, chn));
         } else if ((p->wave128 || p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {

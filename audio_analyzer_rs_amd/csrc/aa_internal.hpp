@@ -102,6 +102,31 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
                            const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0,
                            const Channels *channels = nullptr);
 
+// ---- two frames per wave, n_fft 1024 at hop 256 (the BASELINE geometry) -----------------------
+// stft_wave1024x2_kernel: the two adjacent frames of a wave sit side by side in its half-waves, 16
+// complex points per lane, 512 = 16 x 16 x 2: two radix-16 passes in registers, ONE exchange through
+// LDS and one cross-lane radix-2 (v_permlane16_swap) - no register transpose between passes.
+// Per-lane table [kWave1024x2Rows][64] (build_wave1024x2_table in aa_abi.cpp).
+// LDS: a ring of 11 blocks of 256 samples (the 8 + 3 blocks of a chunk; the next chunk's 8 new blocks
+// overwrite the 8 dead ones once every wave has its frames in registers), four per-wave scratch areas
+// (exchange image with its padding / split strips / row image) and the split-twiddle table [32][16].
+constexpr int kWave1024x2Rows = 95;
+constexpr int kX2RingBlocks = 11;
+constexpr int kX2ParityStride = 296;                  // complex: region of odd source lanes (8 mod 32: the other bank half)
+constexpr int kX2FrameStride = 592;                   // complex: image of the second frame
+constexpr int kX2ScratchDwords = 2 * (kX2FrameStride + kX2ParityStride + 16 * 18);   // 2352 floats = 9408 bytes
+constexpr int kX2RowImage = 2 * 2 * 264;               // floats: the row image of the pair behind the two split strips
+constexpr int kX2TwsStride = 20;                     // floats per lambda: 8 complex + 4 of padding (bank spread)
+constexpr int kX2TwsDwords = 32 * kX2TwsStride + 32;  // + W_32^(2 p + h), [2][16]
+inline size_t wave1024x2_lds_bytes()
+{
+    return sizeof(float) * (size_t)(kX2RingBlocks * 256 + 4 * kX2ScratchDwords + kX2TwsDwords);
+}
+// out_kind: kMag, kPower or kLogPower; hop 256, x and out 16-byte aligned.
+hipError_t launch_wave1024x2(int out_kind, const float *x, float *out, const float *table, int64_t frame_begin,
+                             int64_t n_frames, float log_floor, hipStream_t stream,
+                             const Channels *channels = nullptr);
+
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;
 // behind the rows: the float4 tables the ring variant streams per frame - [8][64] window quadruples,

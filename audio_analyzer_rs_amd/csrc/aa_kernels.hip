@@ -76,6 +76,29 @@ __device__ __forceinline__ void wait_vmcnt_le()
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter on gfx9");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AA_SAFE_WAITS ? 0 : N) : "memory");
 }
+// One LDS-DMA piece (global_load_lds_dwordx4: every lane moves 16 bytes from its own global address to
+// lds_base + 16 lane), issued by hand so that the COMPILER does not know an LDS-DMA is in flight.  For the
+// builtin it does: SIInsertWaitcnts puts an s_waitcnt vmcnt(0) in front of the first DS access that might
+// alias the DMA's destination - with one LDS allocation, every access - i.e. in the middle of the chunk every
+// wave waited for the samples of the NEXT chunk (and for all its row stores), which is exactly what the counted
+// chunk-top waits exist to avoid.  Safety is those waits' job: data moved by a piece is read only behind
+// wait_vmcnt_le<..>() + the workgroup barrier of the chunk that uses it.  lds_base must be wave-uniform.
+#ifndef AA_V_DMA_ASM
+#define AA_V_DMA_ASM 1     // 0: the builtin (compiler-tracked) form, for A/B runs
+#endif
+__device__ __forceinline__ void lds_dma_16(const float *src_lane, float *lds_base)
+{
+    if (AA_V_DMA_ASM) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(lds_base));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :
+                     : "v"(src_lane), "s"(base)
+                     : "memory");   // (m0 is written here and nowhere else in these kernels: the compiler has no use for it on gfx9)
+    } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                         (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+    }
+}
 // Row stores: nontemporal (the rows are written once and not read by this kernel).  AA_V_STORE = 1
 // (experiments): plain stores.
 #ifndef AA_V_STORE
@@ -1490,6 +1513,413 @@ void stft_wave1024_kernel(
     }
     flush_dct();
     AA_CLK_END
+}
+
+// ------------------------------ two frames per wave, n_fft = 1024 at hop 256 (BASELINE geometry) --
+// stft_wave1024x2_kernel: the two ADJACENT frames a wave owns (t = 2 wave, 2 wave + 1 of an 8-frame chunk)
+// sit side by side in its half-waves: frame f in lanes 32 f .. 32 f + 31, SIXTEEN complex points per
+// lane, 512 = 16 x 16 x 2:
+//   pass A  radix-16 over j in registers (lane l reads z[32 j + l], j = 0..15), x W_512^(l k1)
+//   E1      registers <-> lanes through the wave's LDS scratch: lane (f, l) stores T[k1] at complex
+//           f F + (l & 1) P + off[k1] + (l >> 1), lane (f, h, kappa) = 32 f + 16 h + kappa loads the 16
+//           consecutive complex T[kappa][2 i + h] from f F + h P + off[kappa] (8 x ds_read_b128).
+//           off[] = 18 sigma(k1) and P = 296 make both sides bank-conflict free (simulated on the lane
+//           groups of the LDS: tools/wave_sim_1024x2.py)
+//   pass B  radix-16 over i in registers: E_q in the h = 0 lane, O_q in the h = 1 lane, q = 0..15
+//   radix-2 across the lane pair (kappa, 0 | 1): v_permlane16_swap(r[2p], r[2p+1]) hands lane h the pair
+//           (E_q, O_q) for q = 2 p + h; Z[kappa + 16 q] = E_q + W_32^q O_q, Z[.. + 256] = E_q - W_32^q O_q
+//           -> lane lambda = kappa + 16 h holds Z[lambda + 32 r] in register r = 0..15 (natural order)
+//   split   X[k], X[512-k] from Z[k], conj(Z[512-k]), k = lambda + 32 r, r < 8; the partners
+//           (registers 8..15) cross a strip in the scratch; -i W_1024^k from a table in LDS
+//   store   the two rows (one 4104-byte piece, 0 or 2 floats past a 16-byte boundary) staged in the
+//           scratch, 4 nontemporal dwordx4 + 1 dwordx2 per wave as in stft_wave1024_kernel
+// Against stft_wave1024_kernel (8 x 8 x 8, one frame per wave at a time, two interleaved): the 8 x 8
+// register transpose between passes B and C (16 DPP moves + 16 permlane swaps per frame, 148 of that
+// kernel's ~920 VALU cycles per frame) becomes 8 permlane swaps per frame, two twiddle layers of 7/8
+// become 15/16 + 1/2, and the butterfly count stays (two radix-16 = 82 packed instructions per 16
+// points, three radix-8 = 84 per 8 points over... the same 9 stages).  Price: 16 data registers per
+// lane and twice the per-lane constants (window 32, pass-A twiddles 30, W_32 16) -> 3 waves per
+// SIMD, 9.2 KB of exchange scratch per wave -> 3 workgroups per CU.
+// Staging: a ring of 11 blocks of 256 samples (block b of the workgroup's run in slot b mod 11).  A
+// chunk's frames read blocks 8 i .. 8 i + 10; once every wave holds its frames in registers (second
+// barrier) blocks 8 i .. 8 i + 7 are dead and the 8 new blocks of chunk i + 1 land on them by LDS-DMA
+// while chunk i is transformed.
+constexpr int kX2E1Sigma[16] = {2, 11, 6, 15, 0, 9, 4, 13, 8, 1, 12, 5, 10, 3, 14, 7};
+// -i (a - b)
+__device__ __forceinline__ v2f pk_sub_mi(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w for a wave-uniform constant w held in an SGPR pair (VOP3P reads one scalar operand)
+__device__ __forceinline__ v2f pk_cmul_lo_s(v2f a, v2f w)
+{
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    return t;
+}
+__device__ __forceinline__ v2f pk_cmul_hi_s(v2f a, v2f w, v2f t)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// 16-point DFT over the register index, natural order in and out: one radix-2 DIF stage, the odd half
+// times W_16^i (i = 4: the rotation by -i rides in the subtraction), two 8-point DFTs.
+__device__ __forceinline__ void pk_dft16(v2f (&v)[16])
+{
+    const v2f w1 = {0.92387953251128673848f, -0.38268343236508978178f};   // W_16^1
+    const v2f w2 = {0.70710678118654752440f, -0.70710678118654752440f};   // W_16^2
+    const v2f w3 = {0.38268343236508978178f, -0.92387953251128673848f};   // W_16^3
+    const v2f w5 = {-0.38268343236508978178f, -0.92387953251128673848f};  // W_16^5
+    const v2f w6 = {-0.70710678118654752440f, -0.70710678118654752440f};  // W_16^6
+    const v2f w7 = {-0.92387953251128673848f, -0.38268343236508978178f};  // W_16^7
+    v2f a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        a[i] = v[i] + v[i + 8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        b[i] = i == 4 ? pk_sub_mi(v[4], v[12]) : v[i] - v[i + 8];
+    // (every multiply ahead of every dependent FMA: a dependent packed pair back to back costs a wait state)
+    const v2f t1 = pk_cmul_lo_s(b[1], w1), t2 = pk_cmul_lo_s(b[2], w2), t3 = pk_cmul_lo_s(b[3], w3);
+    const v2f t5 = pk_cmul_lo_s(b[5], w5), t6 = pk_cmul_lo_s(b[6], w6), t7 = pk_cmul_lo_s(b[7], w7);
+    pk_dft8(a);
+    b[1] = pk_cmul_hi_s(b[1], w1, t1); b[2] = pk_cmul_hi_s(b[2], w2, t2); b[3] = pk_cmul_hi_s(b[3], w3, t3);
+    b[5] = pk_cmul_hi_s(b[5], w5, t5); b[6] = pk_cmul_hi_s(b[6], w6, t6); b[7] = pk_cmul_hi_s(b[7], w7, t7);
+    pk_dft8(b);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[2 * q] = a[q];
+        v[2 * q + 1] = b[q];
+    }
+}
+__device__ __forceinline__ void lds_wait_16(v2f (&v)[16])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 :
+                 : "memory");
+}
+// packed asm -> permlane read: two wait states, every producer before, every consumer behind (hazard_fence)
+__device__ __forceinline__ void hazard_fence16(v2f (&v)[16])
+{
+    asm volatile("s_nop 1"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+#ifndef AA_X2_PRIO
+#define AA_X2_PRIO 1          // wave-priority rotation of the two-frame kernel: 0 none, 1 three levels at three points
+#endif
+#ifndef AA_X2_ABL
+#define AA_X2_ABL 0           // timing-only ablations (wrong rows): 1 no second barrier and no DMA after the first chunk, 2 no row stores
+#endif
+
+template <int OUT>
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void stft_wave1024x2_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int64_t n_chunks, float log_floor,
+    int n_streams, int64_t stream_in_stride, int64_t stream_out_stride)
+{
+    static_assert(OUT == kMag || OUT == kPower || OUT == kLogPower, "magnitude-type rows only");
+    // Three SEPARATE LDS objects, not one dynamic array: the compiler tracks an LDS-DMA in flight per LDS
+    // object it can tell apart (alias scopes of distinct __shared__ variables) and puts an s_waitcnt vmcnt(0)
+    // in front of the first DS access that may alias it - with a single extern array that is the first
+    // exchange write of every chunk, i.e. every wave would wait there for the samples of the NEXT chunk.
+    __shared__ __attribute__((aligned(16))) float ring[kX2RingBlocks * 256];
+    __shared__ __attribute__((aligned(16))) float scratch[4 * kX2ScratchDwords];
+    __shared__ __attribute__((aligned(16))) float tws_tab[kX2TwsDwords];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = lane >> 5, l = lane & 31;                   // frame of the pair, lane inside the frame
+    int vgrid, vblock;
+    {
+        int64_t in_off, out_off;
+        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
+        x += in_off;
+        out += out_off;
+    }
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1, vgrid, vblock);
+    constexpr int NB = 513, HOP = 256, FPC = 8;               // bins per row, hop, frames per chunk
+    constexpr int kRowStoresPerChunk = 5;                     // 4 dwordx4 + 1 dwordx2 per wave and chunk
+    v2f *scr = reinterpret_cast<v2f *>(scratch + wave * kX2ScratchDwords);
+
+    const int64_t first_frame = (int64_t)c0 * FPC;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)HOP;   // first sample of chunk c
+    float *out_chunk = out + first_frame * NB;
+    int frames_left = (int)(n_frames - first_frame);
+
+    // LDS-DMA of `nblk` consecutive 256-sample blocks from src into ring slots slot_first, +1, .. (mod 11);
+    // wave w moves the blocks w, w + 4, ..
+    auto dma = [&](const float *src, int slot_first, int nblk) {
+        for (int i = wave; i < nblk; i += 4) {
+            int slot = slot_first + i;
+            slot = slot >= kX2RingBlocks ? slot - kX2RingBlocks : slot;
+            lds_dma_16(src + 256 * i + 4 * lane, ring + 256 * slot);
+        }
+    };
+    if (c0 < c1)
+        dma(src_chunk, 0, (frames_left < FPC ? frames_left : FPC) + 3);
+
+    // -i W_1024^(lambda + 32 r) for the split, [lambda][r][re, im]: read once per pass, kept out of the registers
+    // (row stride 20 floats: the 16 lanes of a ds_read_b128 group then start in 16 different bank quads)
+    for (int i = tid; i < 32 * 16; i += kWave1024Threads)
+        tws_tab[kX2TwsStride * (i >> 4) + (i & 15)] = tab[(78 + (i & 15)) * 64 + (i >> 4)];
+    // per-lane constants
+    // W_32^(2 p + h), [h][p][re, im]: two rows, read as broadcasts
+    float *c32_tab = tws_tab + 32 * kX2TwsStride;
+    if (tid < 32)
+        c32_tab[tid] = tab[(62 + (tid & 15)) * 64 + 16 * (tid >> 4)];
+    v2f win[16], twA[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
+    const v4f *c32_rd = reinterpret_cast<const v4f *>(c32_tab + 16 * ((lane >> 4) & 1));
+    const int e1_rd_off = __float_as_int(tab[94 * 64 + lane]);           // complex index of the lane's 16 values
+    v2f *e1_wr = scr + f * kX2FrameStride + (l & 1) * kX2ParityStride + (l >> 1);      // + 18 sigma(k1)
+    const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + e1_rd_off);
+    v2f *strip_wr = scr + f * 264 + l;                                    // + 32 (r - 8)
+    const v2f *strip_rd = scr + f * 264 + 256 - l;                        // - 32 r
+    const v4f *tws_rd = reinterpret_cast<const v4f *>(tws_tab + kX2TwsStride * l);
+    const int tail_lo = lane < 4 ? 0 : lane < 8 ? lane - 4 : 4;
+    const unsigned tail_span = lane < 4 ? (unsigned)lane : lane < 8 ? (unsigned)(7 - lane) : 0u;
+    const unsigned ring_addr = lds_addr(ring) + 8u * (unsigned)l;
+
+    // frames ta (lanes 0-31) and ta + 1 (lanes 32-63) of the chunk whose block 8 it sits in slot s0 -> v
+    const int ta = 2 * wave;
+    auto read_frames = [&](v2f (&v)[16], int s0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned s = (unsigned)(s0 + ta + q) + (unsigned)f;
+            s = min(s, s - (unsigned)kX2RingBlocks);                                     // mod 11 (s < 22): one v_min_u32
+            const unsigned a = ring_addr + 1024u * s;
+            v[4 * q + 0] = lds_read_b64<0>(a);
+            v[4 * q + 1] = lds_read_b64<256>(a);
+            v[4 * q + 2] = lds_read_b64<512>(a);
+            v[4 * q + 3] = lds_read_b64<768>(a);
+        }
+    };
+    // Software pipeline over the chunks: the frames of chunk c + 1 are fetched from the ring while the rows of
+    // chunk c are staged out (the data registers are free by then, and the two LDS round trips - frames in,
+    // row image out - overlap), so the loop body starts with the frames already in registers.
+    //   top of the body      v = frames of chunk c
+    //   ... transform, split, magnitudes, row image ...
+    //   vmcnt(0) + barrier   every wave's LDS-DMA pieces of chunk c + 1 have landed (they were issued a whole
+    //                        chunk ago, in front of the previous rows' stores)
+    //   frame reads (c + 1), row-image reads (c), lgkmcnt(0), row stores (c)
+    //   barrier              every wave holds its frames: blocks 8 it + 8 .. + 15 are dead
+    //   LDS-DMA of chunk c + 2 onto them
+    int slot0 = 0;                                            // slot of block 8 it (first block of chunk c)
+    int it = 0;
+    v2f v[16];
+    bool active = false;                                      // wave-uniform: the wave has a frame in chunk c
+    if (c0 < c1) {
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                        // the first chunk's blocks (and the LDS tables) are in place
+        active = ta < (frames_left < FPC ? frames_left : FPC);
+        if (active) {
+            read_frames(v, 0);
+            lds_wait_16(v);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (c0 + 1 < c1) {
+            const int nleft = frames_left - FPC;
+            dma(src_chunk + (FPC + 3) * HOP, 0, nleft < FPC ? nleft : FPC);
+        }
+    }
+    for (int c = c0; c < c1; ++c, ++it) {
+        const int prio_step = (int)(blockIdx.x >> 8) + 3 * it;
+        if (AA_X2_PRIO == 1)
+            rotate_wave_priority3(prio_step);
+        const int nf = frames_left < FPC ? frames_left : FPC;
+        const bool vb = ta + 1 < nf;                          // lanes 32-63 hold a real frame
+        const bool has_next = c + 1 < c1;
+        const int nf_next = has_next ? (frames_left - FPC < FPC ? frames_left - FPC : FPC) : 0;
+        const bool active_next = ta < nf_next;
+        int slot_next = slot0 + FPC;
+        slot_next = slot_next >= kX2RingBlocks ? slot_next - kX2RingBlocks : slot_next;
+        float *lrow = nullptr;
+        int sh2 = 0;
+        if (active) {
+            // ---- pass A ----
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = v[j] * win[j];
+            pk_dft16(v);
+            {
+                v2f t[16];
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    t[k] = pk_cmul_lo(v[k], twA[k]);
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
+            }
+            // ---- E1 ----
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                e1_wr[18 * kX2E1Sigma[k]] = v[k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const v4f qv = e1_rd[t];
+                v[2 * t] = v2f{qv.x, qv.y};
+                v[2 * t + 1] = v2f{qv.z, qv.w};
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (AA_X2_PRIO == 1)
+                rotate_wave_priority3(prio_step + 1);
+            // ---- pass B + the radix-2 across the lane pair ----
+            pk_dft16(v);
+            hazard_fence16(v);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float ex = v[2 * p].x, ey = v[2 * p].y, ox = v[2 * p + 1].x, oy = v[2 * p + 1].y;
+                xpose_pair_b4(ex, ox);
+                xpose_pair_b4(ey, oy);
+                v[2 * p] = v2f{ex, ey};
+                v[2 * p + 1] = v2f{ox, oy};
+            }
+            v2f z[16];                                        // z[r] = Z[lambda + 32 r]
+            {
+                const v4f ca = c32_rd[0], cb = c32_rd[1], cc = c32_rd[2], cd = c32_rd[3];
+                const v2f c32[8] = {v2f{ca.x, ca.y}, v2f{ca.z, ca.w}, v2f{cb.x, cb.y}, v2f{cb.z, cb.w},
+                                    v2f{cc.x, cc.y}, v2f{cc.z, cc.w}, v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};
+                v2f t[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    t[p] = pk_cmul_lo(v[2 * p + 1], c32[p]);
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    t[p] = pk_cmul_hi(v[2 * p + 1], c32[p], t[p]);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    z[p] = v[2 * p] + t[p];
+                    z[p + 8] = v[2 * p] - t[p];
+                }
+            }
+            // ---- partners Z[512 - k] through the strip ----
+#pragma unroll
+            for (int r = 8; r < 16; ++r)
+                strip_wr[32 * (r - 8)] = z[r];
+            if (l == 0)
+                scr[f * 264 + 256] = z[0];
+            __builtin_amdgcn_wave_barrier();
+            if (AA_X2_PRIO == 1)
+                rotate_wave_priority3(prio_step + 2);
+            // ---- split + magnitudes, four pairs at a time (stage by stage inside a group); the row image
+            // sits behind the strips in the scratch, so a group's values are staged at once ----
+            sh2 = ta & 3;                                     // (8 c + ta) 513 mod 4: 0 or 2
+            lrow = reinterpret_cast<float *>(scr) + kX2RowImage + sh2 + f * NB + l;
+#pragma unroll
+            for (int g = 0; g < 8; g += 4) {
+                v2f prt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    prt[j] = strip_rd[-32 * (g + j)];
+                const v4f twa = tws_rd[g / 2], twb = tws_rd[g / 2 + 1];
+                const v2f tws[4] = {v2f{twa.x, twa.y}, v2f{twa.z, twa.w}, v2f{twb.x, twb.y}, v2f{twb.z, twb.w}};
+                v2f se[4], so[4], st[4], re[4], im[4], pw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    se[j] = pk_add_conj(z[g + j], prt[j]);
+                    so[j] = pk_sub_conj(z[g + j], prt[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    st[j] = pk_cmul_lo(so[j], tws[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    st[j] = pk_cmul_hi(so[j], tws[j], st[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    re[j] = pk_sum_diff_re(se[j], st[j]);
+                    im[j] = pk_sum_diff_im(se[j], st[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pw[j] = re[j] * re[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pw[j] = im[j] * im[j] + pw[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lrow[32 * (g + j)] = bin_from_power<OUT>(pw[j].x, log_floor);
+                    lrow[512 - 2 * l - 32 * (g + j)] = bin_from_power<OUT>(pw[j].y, log_floor);
+                }
+            }
+            const float m256 = bin_value<OUT>(2.0f * z[8].x, 2.0f * z[8].y, log_floor);   // lane lambda = 0 only
+            if (l == 0)
+                lrow[256] = m256;
+        }
+        // ---- the frames of the next chunk come in while the rows of this one go out ----
+        if (has_next && !(AA_X2_ABL & 1)) {
+            wait_vmcnt_le<0>();
+            __builtin_amdgcn_s_barrier();                    // every wave's pieces of chunk c + 1 have landed
+        }
+        if (has_next && active_next)
+            read_frames(v, slot_next);
+        if (active) {
+            // the two rows leave as one piece (stft_wave1024_kernel's adjacent-frame scheme)
+            __builtin_amdgcn_wave_barrier();
+            const float *lw = reinterpret_cast<const float *>(scr) + kX2RowImage;
+            float *gw = out_chunk + ta * NB - sh2;            // 16-byte aligned window of row a
+            if (AA_X2_ABL & 2) {
+                asm volatile("" ::"v"(lw[lane]));
+            } else if (vb) {
+                const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
+                const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
+                const int eo = sh2 ? 2 : 1024;
+                const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
+                if (has_next && active_next)
+                    lds_wait_16(v);
+                __builtin_amdgcn_wave_barrier();
+                v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
+                row_store(q0, gw4);
+                row_store(q1, gw4 + 64);
+                row_store(q2, gw4 + 128);
+                row_store(q3, gw4 + 192);
+                if (lane == 0)
+                    *reinterpret_cast<v2f *>(gw + eo) = edge;
+            } else {
+                // ragged last chunk: only row a exists
+                const v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                const v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
+                const int hi = lane < 4 ? lane : 508 + lane;
+                const float hv = lw[lane < 8 ? hi : 0];
+                __builtin_amdgcn_wave_barrier();
+                row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                if (lane < 63)
+                    row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                if ((unsigned)(sh2 - tail_lo) <= tail_span)
+                    gw[hi] = hv;
+            }
+        }
+        if (has_next && active_next)
+            lds_wait_16(v);                                   // (again for the waves that staged rows out: free)
+        if (has_next && !(AA_X2_ABL & 1)) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();                    // every wave holds its frames of chunk c + 1
+            if (c + 2 < c1) {
+                const int nleft = frames_left - 2 * FPC;
+                dma(src_chunk + (2 * FPC + 3) * HOP, slot_next, nleft < FPC ? nleft : FPC);
+            }
+        }
+        active = active_next;
+        slot0 = slot_next;
+        src_chunk += FPC * HOP;
+        out_chunk += FPC * NB;
+        frames_left -= FPC;
+    }
 }
 
 // ---------------------------------------------------- wave-per-frame, n_fft = 2048 --
@@ -2907,6 +3337,45 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
         return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kMfccR:
         return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, dct_tab, n_mfcc, ch);
+    default:
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int K>
+static hipError_t launch_wave1024x2_kind(const float *x, float *out, const float *table, int64_t frame_begin,
+                                         int64_t n_frames, float log_floor, hipStream_t stream, const Channels &ch)
+{
+    const int64_t chunks = (n_frames + 7) / 8;
+    const size_t lds = 0;                         // the kernel's LDS is static (three objects, see the kernel)
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    if (cached_grid == 0)
+        cached_grid = persistent_grid(stft_wave1024x2_kernel<K>, lds);
+    const int64_t want = experiment_knob("AA_GRID_SET", cached_grid, 1, 1 << 16);
+    const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
+    hipLaunchKernelGGL((stft_wave1024x2_kernel<K>), grid, block, lds, stream, x, out, table, frame_begin, n_frames,
+                       chunks, log_floor, ch.n, ch.in_stride, ch.out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_wave1024x2(int out_kind, const float *x, float *out, const float *table, int64_t frame_begin,
+                             int64_t n_frames, float log_floor, hipStream_t stream, const Channels *channels)
+{
+    const Channels ch = channels ? *channels : Channels();
+    if (ch.n < 1 || (ch.n > 1 && ((ch.in_stride | ch.out_stride) & 3)))
+        return hipErrorInvalidValue;
+    if (n_frames <= 0)
+        return hipSuccess;
+    // LDS-DMA of 16-byte pieces and aligned nontemporal row stores
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) != 0)
+        return hipErrorInvalidValue;
+    switch (out_kind) {
+    case kMag:
+        return launch_wave1024x2_kind<kMag>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
+    case kPower:
+        return launch_wave1024x2_kind<kPower>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
+    case kLogPower:
+        return launch_wave1024x2_kind<kLogPower>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
     default:
         return hipErrorInvalidValue;
     }

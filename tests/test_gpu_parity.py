@@ -54,7 +54,8 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 
 
 def test_kernel_selection(aa):
-    assert aa.Stft(1024, 256).kernel == "wave1024"
+    assert aa.Stft(1024, 256).kernel == "wave1024x2"        # magnitudes at hop 256: two frames per wave
+    assert aa.Stft(1024, 256, output="complex").kernel == "wave1024"
     assert aa.Stft(1024, 100).kernel == "wave1024"          # any hop that keeps 16-byte staging pieces
     assert aa.Stft(1024, 101).kernel == "wg_stockham"
     assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
@@ -77,7 +78,7 @@ def test_wave1024_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
     L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))      # ragged tail is dropped
     x = (0.5 * rng.standard_normal(L)).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == "wave1024"
+    assert plan.kernel == ("wave1024x2" if output == "mag" else "wave1024")
     assert plan.num_frames(L) == n_frames == oracle_mod.num_frames(L, n, hop)
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
@@ -95,7 +96,7 @@ def test_wave1024_hops(aa, oracle_mod, torch_mod, hop):
     rng = np.random.default_rng(hop)
     x = rng.uniform(-1, 1, n + 70 * hop + 5).astype(np.float32)
     plan = aa.Stft(n, hop, output="mag")
-    assert plan.kernel == "wave1024"
+    assert plan.kernel == ("wave1024x2" if hop == 256 else "wave1024")
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind="mag")
     assert got.shape == ref.shape
@@ -902,7 +903,7 @@ def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
     assert np.array_equal(pcm, aa.signals.pcm16_roundtrip(x))
     assert np.max(np.abs(pcm - x)) <= 2.0 / 32768.0                 # truncation + the 32767 / 32768 gain only
     plan = aa.Stft(1024, 256, output="mag")
-    assert plan.kernel == "wave1024"
+    assert plan.kernel == "wave1024x2"
     got = plan(torch_mod.from_numpy(pcm).cuda()).cpu().numpy()
     ref = oracle_mod.stft(pcm, 1024, 256, kind="mag")
     assert got.shape == ref.shape == (11247, 513)
