@@ -991,10 +991,12 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->frames_per_wg = fpw;
                 p->wave1024 = true;
             }
-            // hop 256 (the BASELINE geometry): magnitude-type rows run on the two-frames-per-wave kernel;
-            // AA_W1024_X2=0 at plan creation keeps the 8 x 8 x 8 kernel for them (A/B runs)
+            // hop 256 (the BASELINE geometry): AA_W1024_X2=1 at plan creation runs magnitude-type rows on the
+            // two-frames-per-wave kernel (stft_wave1024x2_kernel: 12.6 % fewer vector instructions, but three
+            // waves per SIMD - measured level with or 2-4 % behind the 8 x 8 x 8 kernel, DESIGN.md section 8;
+            // kept for A/B runs and parity-tested, not the default)
             const char *x2 = std::getenv("AA_W1024_X2");
-            if (p->wave1024 && cfg->hop == 256 && !(x2 && std::atoi(x2) == 0)) {
+            if (p->wave1024 && cfg->hop == 256 && x2 && std::atoi(x2) == 1) {
                 std::vector<float> tab;
                 build_wave1024x2_table(p->window_host.data(), &tab);
                 AA_HIP(hipMalloc(&p->d_w1024x2_tab, tab.size() * sizeof(float)));

@@ -83,8 +83,11 @@ __device__ __forceinline__ void wait_vmcnt_le()
 // wave waited for the samples of the NEXT chunk (and for all its row stores), which is exactly what the counted
 // chunk-top waits exist to avoid.  Safety is those waits' job: data moved by a piece is read only behind
 // wait_vmcnt_le<..>() + the workgroup barrier of the chunk that uses it.  lds_base must be wave-uniform.
+#ifndef AA_V_DMA_AUX
+#define AA_V_DMA_AUX 0     // cache policy bits of the LDS-DMA sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); builtin form only
+#endif
 #ifndef AA_V_DMA_ASM
-#define AA_V_DMA_ASM 1     // 0: the builtin (compiler-tracked) form, for A/B runs
+#define AA_V_DMA_ASM (AA_V_DMA_AUX == 0)     // 0: the builtin (compiler-tracked) form, for A/B runs
 #endif
 __device__ __forceinline__ void lds_dma_16(const float *src_lane, float *lds_base)
 {
@@ -96,7 +99,7 @@ __device__ __forceinline__ void lds_dma_16(const float *src_lane, float *lds_bas
                      : "memory");   // (m0 is written here and nowhere else in these kernels: the compiler has no use for it on gfx9)
     } else {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
-                                         (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)lds_base, 16, 0, AA_V_DMA_AUX);
     }
 }
 // Row stores: nontemporal (the rows are written once and not read by this kernel).  AA_V_STORE = 1
@@ -791,9 +794,6 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_TAIL
 #define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
 #endif
-#ifndef AA_V_DMA_AUX
-#define AA_V_DMA_AUX 0     // cache policy bits of the LDS-DMA sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
 #ifndef AA_V_ILV
 #define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
 #endif
@@ -974,9 +974,7 @@ void stft_wave1024_kernel(
         for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int q = qb + lane;
             if (q < span4)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + 4 * q),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
+                lds_dma_16(src + 4 * q, dst + 4 * qb);
         }
     };
 
@@ -1611,11 +1609,61 @@ __device__ __forceinline__ void hazard_fence16(v2f (&v)[16])
                    "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
 #ifndef AA_X2_PRIO
-#define AA_X2_PRIO 1          // wave-priority rotation of the two-frame kernel: 0 none, 1 three levels at three points
+#define AA_X2_PRIO 11         // wave priority of the two-frame kernel (x2_prio below): 11 measured best, 0 none
+#endif
+#ifndef AA_X2_E1ILV
+#define AA_X2_E1ILV 0         // 1: exchange writes interleaved with the twiddle FMAs (groups of four)
+#endif
+#ifndef AA_X2_E1ORD
+#define AA_X2_E1ORD 0         // 1: exchange reads in the order pass B's first butterflies consume them
 #endif
 #ifndef AA_X2_ABL
 #define AA_X2_ABL 0           // timing-only ablations (wrong rows): 1 no second barrier and no DMA after the first chunk, 2 no row stores
 #endif
+
+// Wave priority of the two-frame kernel at point pt of the chunk body (0 top / pass A, 1 in front of the exchange
+// writes, 2 behind the exchange reads / pass B, 3 in front of the strip writes, 4 behind the strip reads / split,
+// 5 in front of the row-image reads), r = dispatch round of the workgroup + chunk count.  AA_X2_PRIO:
+//   0 none | 1 three levels at points 0, 2, 4 | 4 three levels at 0, 1, 3 (changes in front of the LDS phases)
+//   5 three levels at all six points | 6 static 2 - round | 7 as 1, rotating the other way | 8 as 1 with levels 3..1
+//   9 as 1, the assignment moving on by one every chunk
+__device__ __forceinline__ void x2_prio(int pt, int r)
+{
+    int step = -1;
+    if (AA_X2_PRIO == 1 || AA_X2_PRIO == 7 || AA_X2_PRIO == 8 || AA_X2_PRIO == 9)
+        step = pt == 0 ? 0 : pt == 2 ? 1 : pt == 4 ? 2 : -1;
+    if (AA_X2_PRIO == 4)
+        step = pt == 0 ? 0 : pt == 1 ? 1 : pt == 3 ? 2 : -1;
+    if (AA_X2_PRIO == 5)
+        step = pt;
+    if (AA_X2_PRIO == 6)
+        step = pt == 0 ? 0 : -1;
+    if (AA_X2_PRIO == 11 || AA_X2_PRIO == 12) {          // by phase only, the same in every workgroup: later phases first (11) / last (12)
+        const int lvl = pt == 0 ? 0 : pt == 2 ? 1 : pt == 4 ? 2 : pt == 5 ? 3 : -1;
+        if (lvl == 0) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 0 : 3);
+        if (lvl == 1) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 1 : 2);
+        if (lvl == 2) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 2 : 1);
+        if (lvl == 3) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 3 : 0);
+        return;
+    }
+    if (AA_X2_PRIO == 13) {                               // as 1, and level 3 from the front of each LDS burst to the next rotation point
+        if (pt == 1 || pt == 3 || pt == 5) {
+            __builtin_amdgcn_s_setprio(3);
+            return;
+        }
+        step = pt == 0 ? 0 : pt == 2 ? 1 : 2;
+    }
+    if (step < 0)
+        return;
+    const int k = AA_X2_PRIO == 6 ? r % 3 : AA_X2_PRIO == 7 ? (2 * r + 3 - step % 3) % 3 : (r + step) % 3;
+    const int base = AA_X2_PRIO == 8 ? 1 : 0;
+    if (k == 0)
+        __builtin_amdgcn_s_setprio(2 + base);
+    else if (k == 1)
+        __builtin_amdgcn_s_setprio(1 + base);
+    else
+        __builtin_amdgcn_s_setprio(0 + base);
+}
 
 template <int OUT>
 __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -1646,7 +1694,7 @@ void stft_wave1024x2_kernel(
     int c0, c1;
     chunk_run(n_chunks, c0, c1, vgrid, vblock);
     constexpr int NB = 513, HOP = 256, FPC = 8;               // bins per row, hop, frames per chunk
-    constexpr int kRowStoresPerChunk = 5;                     // 4 dwordx4 + 1 dwordx2 per wave and chunk
+    constexpr int kRowStores = 5;                             // 4 dwordx4 + 1 dwordx2 per wave and full chunk
     v2f *scr = reinterpret_cast<v2f *>(scratch + wave * kX2ScratchDwords);
 
     const int64_t first_frame = (int64_t)c0 * FPC;
@@ -1682,15 +1730,8 @@ void stft_wave1024x2_kernel(
 #pragma unroll
     for (int k = 1; k < 16; ++k)
         twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
-    const v4f *c32_rd = reinterpret_cast<const v4f *>(c32_tab + 16 * ((lane >> 4) & 1));
     const int e1_rd_off = __float_as_int(tab[94 * 64 + lane]);           // complex index of the lane's 16 values
-    v2f *e1_wr = scr + f * kX2FrameStride + (l & 1) * kX2ParityStride + (l >> 1);      // + 18 sigma(k1)
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + e1_rd_off);
-    v2f *strip_wr = scr + f * 264 + l;                                    // + 32 (r - 8)
-    const v2f *strip_rd = scr + f * 264 + 256 - l;                        // - 32 r
-    const v4f *tws_rd = reinterpret_cast<const v4f *>(tws_tab + kX2TwsStride * l);
-    const int tail_lo = lane < 4 ? 0 : lane < 8 ? lane - 4 : 4;
-    const unsigned tail_span = lane < 4 ? (unsigned)lane : lane < 8 ? (unsigned)(7 - lane) : 0u;
     const unsigned ring_addr = lds_addr(ring) + 8u * (unsigned)l;
 
     // frames ta (lanes 0-31) and ta + 1 (lanes 32-63) of the chunk whose block 8 it sits in slot s0 -> v
@@ -1726,10 +1767,8 @@ void stft_wave1024x2_kernel(
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();                        // the first chunk's blocks (and the LDS tables) are in place
         active = ta < (frames_left < FPC ? frames_left : FPC);
-        if (active) {
-            read_frames(v, 0);
-            lds_wait_16(v);
-        }
+        read_frames(v, 0);                                    // (a wave without a frame reads too: no branch around v)
+        lds_wait_16(v);
         __builtin_amdgcn_s_barrier();
         if (c0 + 1 < c1) {
             const int nleft = frames_left - FPC;
@@ -1737,9 +1776,8 @@ void stft_wave1024x2_kernel(
         }
     }
     for (int c = c0; c < c1; ++c, ++it) {
-        const int prio_step = (int)(blockIdx.x >> 8) + 3 * it;
-        if (AA_X2_PRIO == 1)
-            rotate_wave_priority3(prio_step);
+        const int prio_r = (int)(blockIdx.x >> 8) + (AA_X2_PRIO == 9 ? it : 0);      // (the step count of a chunk, 3 or 6, drops out mod 3)
+        x2_prio(0, prio_r);
         const int nf = frames_left < FPC ? frames_left : FPC;
         const bool vb = ta + 1 < nf;                          // lanes 32-63 hold a real frame
         const bool has_next = c + 1 < c1;
@@ -1749,6 +1787,17 @@ void stft_wave1024x2_kernel(
         slot_next = slot_next >= kX2RingBlocks ? slot_next - kX2RingBlocks : slot_next;
         float *lrow = nullptr;
         int sh2 = 0;
+        // The per-lane LDS addresses of the body are re-derived from an opaque copy of the lane index every chunk
+        // (a dozen VALU operations): as loop invariants they would each hold a register for the kernel's lifetime,
+        // and the kernel sits at the 168-register edge of three waves per SIMD.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lf = ln >> 5, ll = ln & 31;
+        v2f *e1_wr = scr + lf * kX2FrameStride + (ll & 1) * kX2ParityStride + (ll >> 1);      // + 18 sigma(k1)
+        v2f *strip_wr = scr + lf * 264 + ll;                                  // + 32 (r - 8)
+        const v2f *strip_rd = scr + lf * 264 + 256 - ll;                      // - 32 r
+        const v4f *tws_rd = reinterpret_cast<const v4f *>(tws_tab + kX2TwsStride * ll);
+        const v4f *c32_rd = reinterpret_cast<const v4f *>(c32_tab + 16 * ((ln >> 4) & 1));
         if (active) {
             // ---- pass A ----
 #pragma unroll
@@ -1760,24 +1809,41 @@ void stft_wave1024x2_kernel(
 #pragma unroll
                 for (int k = 1; k < 16; ++k)
                     t[k] = pk_cmul_lo(v[k], twA[k]);
+                x2_prio(1, prio_r);
+                if (AA_X2_E1ILV) {
+                    // ---- E1 writes handed to the LDS as the twiddled values come out (four at a time), not as
+                    // one burst of sixteen behind the last FMA ----
 #pragma unroll
-                for (int k = 1; k < 16; ++k)
-                    v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
+                    for (int k0 = 0; k0 < 16; k0 += 4) {
+#pragma unroll
+                        for (int k = k0 ? k0 : 1; k < k0 + 4; ++k)
+                            v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
+#pragma unroll
+                        for (int k = k0; k < k0 + 4; ++k)
+                            e1_wr[18 * kX2E1Sigma[k]] = v[k];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 1; k < 16; ++k)
+                        v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
+                    // ---- E1 ----
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        e1_wr[18 * kX2E1Sigma[k]] = v[k];
+                }
             }
-            // ---- E1 ----
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                e1_wr[18 * kX2E1Sigma[k]] = v[k];
             __builtin_amdgcn_wave_barrier();
+            // (read order 0, 4, 1, 5, ..: the first butterflies of pass B pair register i with i + 8)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = AA_X2_E1ORD ? (tt >> 1) + 4 * (tt & 1) : tt;
                 const v4f qv = e1_rd[t];
                 v[2 * t] = v2f{qv.x, qv.y};
                 v[2 * t + 1] = v2f{qv.z, qv.w};
             }
             __builtin_amdgcn_wave_barrier();
-            if (AA_X2_PRIO == 1)
-                rotate_wave_priority3(prio_step + 1);
+            x2_prio(2, prio_r);
             // ---- pass B + the radix-2 across the lane pair ----
             pk_dft16(v);
             hazard_fence16(v);
@@ -1808,18 +1874,18 @@ void stft_wave1024x2_kernel(
                 }
             }
             // ---- partners Z[512 - k] through the strip ----
+            x2_prio(3, prio_r);
 #pragma unroll
             for (int r = 8; r < 16; ++r)
                 strip_wr[32 * (r - 8)] = z[r];
-            if (l == 0)
-                scr[f * 264 + 256] = z[0];
+            if (ll == 0)
+                scr[lf * 264 + 256] = z[0];
             __builtin_amdgcn_wave_barrier();
-            if (AA_X2_PRIO == 1)
-                rotate_wave_priority3(prio_step + 2);
+            x2_prio(4, prio_r);
             // ---- split + magnitudes, four pairs at a time (stage by stage inside a group); the row image
             // sits behind the strips in the scratch, so a group's values are staged at once ----
             sh2 = ta & 3;                                     // (8 c + ta) 513 mod 4: 0 or 2
-            lrow = reinterpret_cast<float *>(scr) + kX2RowImage + sh2 + f * NB + l;
+            lrow = reinterpret_cast<float *>(scr) + kX2RowImage + sh2 + lf * NB + ll;
 #pragma unroll
             for (int g = 0; g < 8; g += 4) {
                 v2f prt[4];
@@ -1854,35 +1920,62 @@ void stft_wave1024x2_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     lrow[32 * (g + j)] = bin_from_power<OUT>(pw[j].x, log_floor);
-                    lrow[512 - 2 * l - 32 * (g + j)] = bin_from_power<OUT>(pw[j].y, log_floor);
+                    lrow[512 - 2 * ll - 32 * (g + j)] = bin_from_power<OUT>(pw[j].y, log_floor);
                 }
             }
             const float m256 = bin_value<OUT>(2.0f * z[8].x, 2.0f * z[8].y, log_floor);   // lane lambda = 0 only
-            if (l == 0)
+            if (ll == 0)
                 lrow[256] = m256;
         }
         // ---- the frames of the next chunk come in while the rows of this one go out ----
+        // Order of the vector-memory operations of a wave: .. DMA(c + 1) | stores(c - 1) .. DMA(c + 2) | stores(c) ..
+        // - the rows are stored BEHIND the next LDS-DMA, so that waiting for a DMA (vmcnt retires in order) never
+        // waits for row stores: the wait below leaves exactly the kRowStores stores of the previous chunk in flight
+        // (none were issued yet in the first pass: full wait).
+        x2_prio(5, prio_r);
         if (has_next && !(AA_X2_ABL & 1)) {
-            wait_vmcnt_le<0>();
+            if (it == 0)
+                wait_vmcnt_le<0>();
+            else
+                wait_vmcnt_le<kRowStores>();
             __builtin_amdgcn_s_barrier();                    // every wave's pieces of chunk c + 1 have landed
         }
-        if (has_next && active_next)
-            read_frames(v, slot_next);
+        // Every wave reads, whether or not the next chunk exists or holds a frame for it (the addresses are valid
+        // either way, the values unused): branches around the sixteen data registers cost register copies at
+        // every merge.
+        read_frames(v, slot_next);
+        // the two rows leave as one piece (stft_wave1024_kernel's adjacent-frame scheme): image -> registers now,
+        // registers -> memory behind the barrier and the DMA
+        const float *lw = reinterpret_cast<const float *>(scr) + kX2RowImage;
+        float *gw = out_chunk + ta * NB - sh2;                // 16-byte aligned window of row a
+        const int eo = sh2 ? 2 : 1024;
+        const int hi = lane < 4 ? lane : 508 + lane;
+        v4f q0, q1, q2, q3;
+        v2f edge;
+        float hv = 0.0f;
         if (active) {
-            // the two rows leave as one piece (stft_wave1024_kernel's adjacent-frame scheme)
             __builtin_amdgcn_wave_barrier();
-            const float *lw = reinterpret_cast<const float *>(scr) + kX2RowImage;
-            float *gw = out_chunk + ta * NB - sh2;            // 16-byte aligned window of row a
-            if (AA_X2_ABL & 2) {
-                asm volatile("" ::"v"(lw[lane]));
-            } else if (vb) {
+            if (vb) {
                 const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
-                const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
-                const int eo = sh2 ? 2 : 1024;
-                const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
-                if (has_next && active_next)
-                    lds_wait_16(v);
-                __builtin_amdgcn_wave_barrier();
+                q0 = lw4[0]; q1 = lw4[64]; q2 = lw4[128]; q3 = lw4[192];
+                edge = *reinterpret_cast<const v2f *>(lw + eo);
+            } else {
+                // ragged last chunk: only row a exists
+                q0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
+                q1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
+                hv = lw[lane < 8 ? hi : 0];
+            }
+        }
+        lds_wait_16(v);                                       // frames and row image are in registers
+        if (has_next && !(AA_X2_ABL & 1)) {
+            __builtin_amdgcn_s_barrier();                    // every wave holds its frames of chunk c + 1
+            if (c + 2 < c1) {
+                const int nleft = frames_left - 2 * FPC;
+                dma(src_chunk + (2 * FPC + 3) * HOP, slot_next, nleft < FPC ? nleft : FPC);
+            }
+        }
+        if (active && !(AA_X2_ABL & 2)) {
+            if (vb) {
                 v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
                 row_store(q0, gw4);
                 row_store(q1, gw4 + 64);
@@ -1891,27 +1984,12 @@ void stft_wave1024x2_kernel(
                 if (lane == 0)
                     *reinterpret_cast<v2f *>(gw + eo) = edge;
             } else {
-                // ragged last chunk: only row a exists
-                const v4f b0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
-                const v4f b1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
-                const int hi = lane < 4 ? lane : 508 + lane;
-                const float hv = lw[lane < 8 ? hi : 0];
-                __builtin_amdgcn_wave_barrier();
-                row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
+                row_store(q0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
                 if (lane < 63)
-                    row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                if ((unsigned)(sh2 - tail_lo) <= tail_span)
+                    row_store(q1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
+                // head floats sh2..3 (lanes 0-3) and tail floats 512..512+sh2 (lanes 4-7)
+                if (lane < 4 ? lane >= sh2 : (lane < 8 && lane - 4 <= sh2))
                     gw[hi] = hv;
-            }
-        }
-        if (has_next && active_next)
-            lds_wait_16(v);                                   // (again for the waves that staged rows out: free)
-        if (has_next && !(AA_X2_ABL & 1)) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();                    // every wave holds its frames of chunk c + 1
-            if (c + 2 < c1) {
-                const int nleft = frames_left - 2 * FPC;
-                dma(src_chunk + (2 * FPC + 3) * HOP, slot_next, nleft < FPC ? nleft : FPC);
             }
         }
         active = active_next;
@@ -2074,9 +2152,7 @@ void stft_wave2048_kernel(
         for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int q = qb + lane;
             if (q < span4)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + 4 * q),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
+                lds_dma_16(src + 4 * q, dst + 4 * qb);
         }
     };
     // RING: blocks [have, need_end) of the workgroup's sample run into their ring slots; wave w moves
@@ -2086,9 +2162,7 @@ void stft_wave2048_kernel(
     auto ring_dma = [&](int need_end) {
         int issued = 0;
         for (int b = have + wave; b < need_end; b += 4, ++issued)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src_wg + 256 * b),
-                (__attribute__((address_space(3))) void *)(smem + 256 * (b % RB)), 16, 0, AA_V_DMA_AUX);
+            lds_dma_16(src_wg + 256 * b, smem + 256 * (b % RB));
         if (need_end > have)
             have = need_end;
         return issued;
@@ -2546,9 +2620,7 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int qq = qb + lane;
             if (qq < span4)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + 4 * qq),
-                    (__attribute__((address_space(3))) void *)(dst + 4 * qb), 16, 0, AA_V_DMA_AUX);
+                lds_dma_16(src + 4 * qq, dst + 4 * qb);
         }
     };
     if (c0 < c1)

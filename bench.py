@@ -338,7 +338,7 @@ def run_single(args):
     x = aa.signals.synth_corpus(0, SAMPLES_10MIN)
     xd = torch.from_numpy(x).to(dev)
     plan = aa.Stft(N_FFT, HOP, output="mag")
-    assert plan.kernel == "wave1024x2", plan.kernel
+    assert plan.kernel == "wave1024", plan.kernel
     nf = plan.num_frames(xd.shape[0])
     out = torch.empty((nf, plan.cols), dtype=torch.float32, device=dev)
     timer = GpuTimer(torch, dev)

@@ -54,8 +54,7 @@ def test_golden_vectors_through_abi(aa, golden, n, hop, name):
 
 
 def test_kernel_selection(aa):
-    assert aa.Stft(1024, 256).kernel == "wave1024x2"        # magnitudes at hop 256: two frames per wave
-    assert aa.Stft(1024, 256, output="complex").kernel == "wave1024"
+    assert aa.Stft(1024, 256).kernel == "wave1024"
     assert aa.Stft(1024, 100).kernel == "wave1024"          # any hop that keeps 16-byte staging pieces
     assert aa.Stft(1024, 101).kernel == "wg_stockham"
     assert aa.Stft(2048, 512).kernel == "wave2048"          # tuner geometry (stft.rs:169-170)
@@ -78,7 +77,7 @@ def test_wave1024_vs_oracle(aa, oracle_mod, torch_mod, n_frames, output):
     L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))      # ragged tail is dropped
     x = (0.5 * rng.standard_normal(L)).astype(np.float32)
     plan = aa.Stft(n, hop, output=output)
-    assert plan.kernel == ("wave1024x2" if output == "mag" else "wave1024")
+    assert plan.kernel == "wave1024"
     assert plan.num_frames(L) == n_frames == oracle_mod.num_frames(L, n, hop)
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind=output)
@@ -96,7 +95,7 @@ def test_wave1024_hops(aa, oracle_mod, torch_mod, hop):
     rng = np.random.default_rng(hop)
     x = rng.uniform(-1, 1, n + 70 * hop + 5).astype(np.float32)
     plan = aa.Stft(n, hop, output="mag")
-    assert plan.kernel == ("wave1024x2" if hop == 256 else "wave1024")
+    assert plan.kernel == "wave1024"
     got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
     ref = oracle_mod.stft(x, n, hop, kind="mag")
     assert got.shape == ref.shape
@@ -217,6 +216,51 @@ def test_wave1024_power_and_logpower(aa, oracle_mod, torch_mod):
     assert nerr(10.0 ** (got_l.astype(np.float64) / 10.0), np.maximum(P, 1e-10)).max() < 4 * TOL_VS_TRUTH
     near = ref_l >= ref_l.max(axis=1, keepdims=True) - 40.0
     assert np.max(np.abs(got_l - ref_l)[near]) < 1e-3
+
+
+def test_two_frames_per_wave_kernel_opt_in(aa, oracle_mod, torch_mod, monkeypatch):
+    """stft_wave1024x2_kernel (AA_W1024_X2=1 at plan creation; 512 = 16 x 16 x 2, two frames side by side in
+    the half-waves; not the default: DESIGN.md section 8) against the CPU oracle and the float64 truth:
+    ragged frame counts around the 8-frame chunk and the ring of 11 blocks, sub-ranges, power / log-power,
+    two channels in one launch, and the same rows as the default kernel to rounding."""
+    monkeypatch.setenv("AA_W1024_X2", "1")
+    n, hop = 1024, 256
+    plan = aa.Stft(n, hop, output="mag")
+    assert plan.kernel == "wave1024x2"
+    monkeypatch.delenv("AA_W1024_X2")
+    ref_plan = aa.Stft(n, hop, output="mag")
+    assert ref_plan.kernel == "wave1024"
+    w = oracle_mod.hann_window(n)
+    for n_frames in (1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 87, 88, 89, 1000, 4099):
+        rng = np.random.default_rng(n_frames)
+        L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
+        x = (0.5 * rng.standard_normal(L)).astype(np.float32)
+        xd = torch_mod.from_numpy(x).cuda()
+        buf = torch_mod.full((n_frames * 513 + 64,), float("nan"), device="cuda")
+        got = plan.execute_device(xd, 0, n_frames, out=buf[:n_frames * 513].view(n_frames, 513))
+        torch_mod.cuda.synchronize()
+        assert torch_mod.isnan(buf[n_frames * 513:]).all(), "wrote past the slab"
+        got = got.cpu().numpy()
+        assert nerr(got, oracle_mod.stft(x, n, hop, kind="mag").astype(np.float64)).max() < TOL_VS_ORACLE
+        assert nerr(got, np.abs(oracle_mod.truth.stft_complex(x, n, hop, w))).max() < TOL_VS_TRUTH
+        assert nerr(got, ref_plan(xd).cpu().numpy().astype(np.float64)).max() < 2e-6
+    x = aa.signals.synth_corpus(5, n + 999 * hop)
+    xd = torch_mod.from_numpy(x).cuda()
+    full = plan(xd).cpu().numpy()
+    for f0, f1 in ((1, 1000), (7, 13), (8, 9), (123, 999), (500, 501)):
+        assert np.array_equal(plan.execute_device(xd, f0, f1).cpu().numpy(), full[f0:f1])
+    monkeypatch.setenv("AA_W1024_X2", "1")
+    P = np.abs(oracle_mod.truth.stft_complex(x, n, hop, w)) ** 2
+    pw = aa.Stft(n, hop, output="power")
+    assert pw.kernel == "wave1024x2"
+    assert nerr(pw(xd).cpu().numpy(), P).max() < 2 * TOL_VS_TRUTH
+    lg = aa.Stft(n, hop, output="logpower")(xd).cpu().numpy()
+    assert nerr(10.0 ** (lg.astype(np.float64) / 10.0), np.maximum(P, 1e-10)).max() < 4 * TOL_VS_TRUTH
+    # two planar channels in one launch (aa_stft_execute_channels_device): rows equal to per-channel launches
+    y = aa.signals.synth_corpus(6, n + 999 * hop, seed=54321)
+    both = torch_mod.from_numpy(np.stack([x, y])).cuda()
+    rows = plan.execute_channels_device(both).cpu().numpy()
+    assert np.array_equal(rows[0], full) and np.array_equal(rows[1], plan(torch_mod.from_numpy(y).cuda()).cpu().numpy())
 
 
 def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
@@ -903,7 +947,7 @@ def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
     assert np.array_equal(pcm, aa.signals.pcm16_roundtrip(x))
     assert np.max(np.abs(pcm - x)) <= 2.0 / 32768.0                 # truncation + the 32767 / 32768 gain only
     plan = aa.Stft(1024, 256, output="mag")
-    assert plan.kernel == "wave1024x2"
+    assert plan.kernel == "wave1024"
     got = plan(torch_mod.from_numpy(pcm).cuda()).cpu().numpy()
     ref = oracle_mod.stft(pcm, 1024, 256, kind="mag")
     assert got.shape == ref.shape == (11247, 513)

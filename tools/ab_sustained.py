@@ -42,9 +42,12 @@ for rep in range(3):
 print(" ".join("%.2f" % r for r in res))
 """
 
+# a library may carry environment settings for its child process: path@NAME=VALUE[@NAME=VALUE..]
 libs = [a for a in sys.argv[1:] if not a.isdigit()]
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 for r in range(rounds):
     for lib in libs:
-        out = subprocess.check_output([sys.executable, "-c", CHILD, lib]).decode().strip().splitlines()[-1]
+        path, *sets = lib.split("@")
+        env = dict(os.environ, **dict(kv.split("=", 1) for kv in sets))
+        out = subprocess.check_output([sys.executable, "-c", CHILD, path], env=env, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1]
         print(f"round {r} {os.path.basename(lib):32s} us/step: {out}", flush=True)
