@@ -233,6 +233,12 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     geometry("mag_2048_512", 2048, 512, "mag", 512 * 4 + 1025 * 4)
     geometry("mag_256_64", 256, 64, "mag", 64 * 4 + 129 * 4)
     geometry("complex_1024_256", 1024, 256, "complex", 256 * 4 + 513 * 8)
+    # the opt-in two-frames-per-wave kernel of the headline geometry (16 x 16 x 2), for the record
+    os.environ["AA_W1024_X2"] = "1"
+    try:
+        geometry("mag_1024_256_x2", N_FFT, HOP, "mag", BYTES_PER_FRAME)
+    finally:
+        del os.environ["AA_W1024_X2"]
 
     # configs[2]: 2048-pt + 128 log-mel on synthetic stereo (two channels, seeds 12345 / 54321)
     n_mels = 128
