@@ -806,6 +806,9 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_SHARE
 #define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
 #endif
+#ifndef AA_V_PIPE
+#define AA_V_PIPE 0        // PAIR: the frames of chunk c + 1 are read from LDS while the rows of chunk c are staged out
+#endif
 #ifndef AA_V_SPLIT
 #define AA_V_SPLIT 1       // uneven chunk runs: the remainder goes to the workgroups dispatched first
 #endif
@@ -899,9 +902,9 @@ __device__ __forceinline__ void rotate_wave_priority3(int step)
 // strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines,
 // 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80), 1024 no
 // priority rotation.
-template <int OUT, int ABL = 0, bool WIDE = false>
+template <int OUT, int ABL = 0, bool WIDE = false, bool PIPE = false>
 __global__ __launch_bounds__(kWave1024Threads)
-__attribute__((amdgpu_waves_per_eu(OUT == kMfccR ? 3 : 1)))      // kMfccR: stay within 168 VGPRs (3 waves per SIMD)
+__attribute__((amdgpu_waves_per_eu(OUT == kMfccR ? 3 : PIPE ? 4 : 1)))      // kMfccR: stay within 168 VGPRs (3 waves per SIMD); PIPE: within 128
 void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
@@ -1024,8 +1027,32 @@ void stft_wave1024_kernel(
         }
     };
     int it = 0;
+    // AA_V_PIPE (PAIR, 8 frames per chunk): software pipeline over the chunks - the barrier that says "chunk c + 1
+    // has landed", the LDS-DMA of chunk c + 2 and the frame reads of chunk c + 1 sit at the END of chunk c's body,
+    // between the staging of its rows and their reads (pipe_hook below), so that the two LDS round trips overlap
+    // and the body starts with its frames already in registers; the classic chunk top runs for the first chunk only.
+    static_assert(!PIPE || (PAIR && !AA_V_ILV && !(ABL & 8)), "PIPE is a variant of the adjacent-frame magnitude path");
+    constexpr bool pipe = PIPE;                              // (the launcher instantiates it for 8 frames per chunk only)
+    v2f va[8], vbv[8];
+    if (pipe && c0 < c1) {
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
+        if (c0 + cstep < c1) {
+            const int nleft = frames_left - frames_step;
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, 1);
+        }
+        const unsigned fb = smem_addr + 4u * (unsigned)(2 * lane) + 4u * (unsigned)(2 * wave * hop);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)                          // (a wave without a frame reads too: no branch around the registers)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(va[j]) : "v"(fb), "n"(512 * j) : "memory");
+        lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+    }
     for (int c = c0; c < c1; c += cstep, ++it) {
         const int cur = it & 1;
+        const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        const int prio_step = (int)(blockIdx.x >> 8) + 4 * it;   // dispatch round + quarter chunks
+        if (!pipe) {
         // The DMA loads of this chunk were issued before the previous chunk's row stores, and
         // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
@@ -1039,19 +1066,45 @@ void stft_wave1024_kernel(
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        const int prio_step = (int)(blockIdx.x >> 8) + 4 * it;   // dispatch round + quarter chunks
         if (!(ABL & 1024))
             rotate_wave_priority(prio_step);
-        const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         if (c + cstep < c1 && !(ABL & 8)) {
             const int nleft = frames_left - frames_step;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
+        } else if (!(ABL & 1024))
+            rotate_wave_priority(prio_step);
         flush_dct();
         const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
 
         // ---- per-frame phases (lambdas so that two frames can be interleaved) ----------
+        auto read_frame_at = [&](unsigned base, int t, v2f (&v)[8]) {
+            const unsigned fr = base + 4u * (unsigned)(t * hop);
+            v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<512>(fr); v[2] = lds_read_b64<1024>(fr);
+            v[3] = lds_read_b64<1536>(fr); v[4] = lds_read_b64<2048>(fr); v[5] = lds_read_b64<2560>(fr);
+            v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
+        };
+        // pipe: in front of the row-image reads of the chunk's last epilogue (every wave of a full chunk passes here)
+        const bool has_next = c + cstep < c1;
+        auto pipe_hook = [&]() {
+            if (!has_next)
+                return;
+            if (it == 0)
+                wait_vmcnt_le<0>();                  // the DMA of chunk 1 was issued at the top: no stores behind it yet
+            else
+                wait_vmcnt_le<kRowStoresPerChunk>(); // .. DMA(c + 1) | stores(c - 1): leave those in flight
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();            // chunk c + 1 has landed; every wave is done with buffer `cur`
+            if (c + 2 * cstep < c1) {
+                const int nleft = frames_left - 2 * frames_step;
+                stage(src_chunk + 2 * src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur);
+            }
+            int lh = lane;
+            asm volatile("" : "+v"(lh));             // (opaque: a hoisted address would be spilled and reloaded behind the DMA)
+            const unsigned nb = smem_addr + 4u * (unsigned)((cur ^ 1) * max_span + 2 * lh);
+            read_frame_at(nb, 2 * wave, va);                 // (frame b is read at the top of the next body, under pass A of frame a)
+        };
         auto read_frame = [&](int t, v2f (&v)[8]) {
             const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
             v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<512>(fr); v[2] = lds_read_b64<1024>(fr);
@@ -1071,16 +1124,24 @@ void stft_wave1024_kernel(
             }
             pk_twiddle7(v, twA);
         };
+        // PIPE: the exchange addresses are re-derived from an opaque copy of the lane index every chunk (four VALU
+        // operations) instead of holding two registers for the kernel's lifetime: the variant carries frame a's
+        // eight register pairs across the loop edge and must stay within 128 registers
+        int lx = lane;
+        if (PIPE)
+            asm volatile("" : "+v"(lx));
+        v2f *e1_wr_c = PIPE ? scr + 66 * (lx & 7) + (lx >> 3) : e1_wr;
+        const v4f *e1_rd_c = PIPE ? reinterpret_cast<const v4f *>(scr + 8 * (lx & 7) + 66 * (lx >> 3)) : e1_rd;
         auto exchange1 = [&](v2f (&v)[8]) {           // E1 through LDS
             if (ABL & 4)
                 return;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
-                e1_wr[8 * kk] = v[kk];
+                e1_wr_c[8 * kk] = v[kk];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v4f qv = e1_rd[i];
+                v4f qv = e1_rd_c[i];
                 v[2 * i] = v2f{qv.x, qv.y};
                 v[2 * i + 1] = v2f{qv.z, qv.w};
             }
@@ -1271,10 +1332,14 @@ void stft_wave1024_kernel(
                     const float *lw = reinterpret_cast<const float *>(scr);
                     float *gw = row - NB - sh2;                          // window of row a
                     if (valid) {
+                        if (pipe)
+                            pipe_hook();
                         const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
                         const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
                         const int eo = sh2 ? 2 : 1024;
                         const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
+                        if (pipe && has_next)
+                            lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
                         __builtin_amdgcn_wave_barrier();
                         v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
                         row_store(q0, gw4);
@@ -1293,7 +1358,7 @@ void stft_wave1024_kernel(
                         row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
                         if (lane < 63)
                             row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                        if ((unsigned)(sh2 - tail_lo) <= tail_span)
+                        if (PIPE ? (lane < 4 ? lane >= sh2 : (lane < 8 && lane - 4 <= sh2)) : (unsigned)(sh2 - tail_lo) <= tail_span)
                             gw[hi] = hv;
                     }
                 }
@@ -1348,12 +1413,23 @@ void stft_wave1024_kernel(
             const int ta = PAIR ? 2 * wave : wave, tb = PAIR ? 2 * wave + 1 : wave + 4;
             if (ta < nf) {
                 const bool vb = tb < nf;   // ragged last chunk: B computes on stale LDS, stores nothing
-                v2f va[8], vbv[8], pa[4], pb[4];
+                v2f pa[4], pb[4];
                 // AA_V_SHARE: adjacent frames at hop 256 overlap by six of the eight 128-float blocks a
                 // lane reads (block j of frame b = block j + 2 of frame a, same lane): frame b loads
                 // only its last two blocks and takes the others from frame a's registers
                 const bool share = AA_V_SHARE && PAIR && hop == 256;
-                read_frame(ta, va);
+                if (pipe) {
+                    // frame a is in registers since the prologue / the previous chunk's pipe_hook; frame b's reads
+                    // fly under pass A of frame a
+                    read_frame(tb, vbv);
+                } else if (!share) {
+                    read_frame(ta, va);
+                    read_frame(tb, vbv);
+                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                }
+                if (share)
+                    read_frame(ta, va);
                 if (share) {
                     const unsigned frb = buf_addr + 4u * (unsigned)(tb * hop);
                     vbv[6] = lds_read_b64<3072>(frb);
@@ -1365,15 +1441,13 @@ void stft_wave1024_kernel(
                         vbv[j] = va[j + 2] * win[j];
                     vbv[6] = vbv[6] * win[6];
                     vbv[7] = vbv[7] * win[7];
-                } else {
-                    read_frame(tb, vbv);
-                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 }
                 pass_a(va);
                 exchange1(va);
                 if (!(ABL & 1024))
                     rotate_wave_priority(prio_step + 1);
+                if (pipe)
+                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 pass_a(vbv, share);
                 exchange1(vbv);
                 if (!(ABL & 1024))
@@ -3363,7 +3437,12 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
 #ifndef AA_V_ABL
 #define AA_V_ABL 0      // experiments: an ablation / variant mask of stft_wave1024_kernel in the product launcher
 #endif
-    if (wide)
+    constexpr bool kPipeKind = AA_V_PIPE && AA_V_PAIR && !AA_V_ILV && !(AA_V_ABL & 8) && (K == kMag || K == kPower || K == kLogPower);
+    if (wide && kPipeKind && frames_per_wg == 8)
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true, kPipeKind>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
+                           ch.n, ch.in_stride, ch.out_stride);
+    else if (wide)
         hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
                            ch.n, ch.in_stride, ch.out_stride);

@@ -155,7 +155,7 @@ def cpu_baseline(x, min_seconds=8.0, max_reps=20):
 def load_traffic():
     """HBM bytes per launch of the headline kernel from the committed PMC passes (NOT measured in
     this run): (bytes, source file)."""
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -193,6 +193,8 @@ class GpuTimer:
         for _ in range(steps):
             fn()
         e1.record(self.stream)
+        while not e1.query():                      # poll: a blocking wait adds the host's wake-up latency to K short steps
+            pass
         torch.cuda.synchronize(self.dev)
         wall = time.perf_counter() - t0
         return e0.elapsed_time(e1) / steps, wall
