@@ -38,7 +38,7 @@ def test_counted_wait_inputs_match_the_verified_build(fresh):
     bad = []
     for name, g in golden["kernels"].items():
         k = fresh["kernels"][name]
-        for key in ("global_store", "global_load_lds", "vmcnt_waits", "scratch_bytes"):
+        for key in ("global_store", "global_load_lds", "vmcnt_waits", "scratch_bytes", "m0_other_uses"):
             if k[key] != g[key]:
                 bad.append((name, key, g[key], k[key]))
         if waves_per_simd(k["vgprs"]) != waves_per_simd(g["vgprs"]):
@@ -49,10 +49,11 @@ def test_counted_wait_inputs_match_the_verified_build(fresh):
 def test_no_wave_kernel_spills_and_occupancy_as_planned(fresh):
     for name, k in fresh["kernels"].items():
         assert k["scratch_bytes"] == 0, (name, k)
+        assert k["m0_other_uses"] == 0, (name, k)        # m0 belongs to the hand-issued LDS-DMA alone
         if name.startswith("stft_wave1024_kernel<") and name.split("<")[1][0] in "0123":
             assert waves_per_simd(k["vgprs"]) == 4, (name, k)        # four workgroups of four waves per CU
         if name.startswith("stft_wave1024x2_kernel") or name.startswith("stft_wave2048_kernel"):
             assert waves_per_simd(k["vgprs"]) >= 3, (name, k)
     # the bench kernel's counted wait leaves its five row stores (4 dwordx4 + 1 dwordx2 per frame pair) in flight
-    assert 5 in fresh["kernels"]["stft_wave1024_kernel<1, 0, true>"]["vmcnt_waits"]
+    assert 5 in fresh["kernels"]["stft_wave1024_kernel<1, 0, true, false>"]["vmcnt_waits"]
     assert 5 in fresh["kernels"]["stft_wave1024x2_kernel<1>"]["vmcnt_waits"]

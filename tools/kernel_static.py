@@ -54,6 +54,10 @@ def facts():
         res[name]["global_store"] = len(re.findall(r"^\s+global_store_", body, re.M))
         res[name]["global_load_lds"] = len(re.findall(r"^\s+global_load_lds_", body, re.M))
         res[name]["vmcnt_waits"] = sorted(set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)))
+        # lds_dma_16 writes m0 by hand (s_mov_b32 m0, sN) without telling the compiler: no other instruction of the kernel may
+        # read or write it
+        res[name]["m0_other_uses"] = len([l for l in body.splitlines() if re.search(r"\bm0\b", l.split(";")[0])
+                                          and not re.match(r"\s+s_mov_b32 m0, s\d+", l)])
     names = sorted(n for n in res if WAVE.search(n))
     pretty = demangle(names)
     out = {}
