@@ -852,6 +852,11 @@ __device__ __forceinline__ void stream_of_block(int n_streams, int64_t in_stride
 #ifndef AA_PRIO_ROTATE
 #define AA_PRIO_ROTATE 1      // 0: diagnostic builds without the rotation (tools/ab_sustained.py)
 #endif
+#ifndef AA_W1024_PRIO
+#define AA_W1024_PRIO -1   // stft_wave1024_kernel: 0 the four-level rotation; abcd: priority by phase, the same in every workgroup - level
+#endif                     // a from the chunk top, b behind frame a's first exchange, c behind frame b's, d from the epilogues on;
+                           // -1 (shipped): 3310 for complex rows (-1.5 %: 91.9 -> 90.5 us), the rotation for every other kind (r3
+                           // sweep: magnitudes level with 3310 / 2210 / 3320 and +1 % with 3210, log-mel +9 %, MFCC +5 % by phase)
 __device__ __forceinline__ void rotate_wave_priority(int step)
 {
     if (!AA_PRIO_ROTATE)
@@ -878,6 +883,21 @@ __device__ __forceinline__ void rotate_wave_priority3(int step)
     case 1: __builtin_amdgcn_s_setprio(1); break;
     default: __builtin_amdgcn_s_setprio(0); break;
     }
+}
+
+template <int PATTERN>
+__device__ __forceinline__ void w1024_prio(int point, int prio_step)
+{
+    if (PATTERN == 0) {
+        rotate_wave_priority(prio_step + point);
+        return;
+    }
+    const int lvl = point == 0 ? (PATTERN / 1000) % 10 : point == 1 ? (PATTERN / 100) % 10
+                  : point == 2 ? (PATTERN / 10) % 10 : PATTERN % 10;
+    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+    if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    if (lvl == 3) __builtin_amdgcn_s_setprio(3);
 }
 
 // ---------------------------------------------------- wave-per-frame, n_fft = 1024 --
@@ -942,6 +962,7 @@ void stft_wave1024_kernel(
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
+    constexpr int kPrioPattern = AA_W1024_PRIO >= 0 ? AA_W1024_PRIO : OUT == kComplex ? 3310 : 0;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR;
     constexpr bool PAIR = AA_V_PAIR && WIDE && !MEL && OUT != kComplex;
     // global stores a wave issues for its two rows of a full 8-frame chunk (every one is issued by
@@ -1067,13 +1088,13 @@ void stft_wave1024_kernel(
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         if (!(ABL & 1024))
-            rotate_wave_priority(prio_step);
+            w1024_prio<kPrioPattern>(0, prio_step);
         if (c + cstep < c1 && !(ABL & 8)) {
             const int nleft = frames_left - frames_step;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
         } else if (!(ABL & 1024))
-            rotate_wave_priority(prio_step);
+            w1024_prio<kPrioPattern>(0, prio_step);
         flush_dct();
         const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
         const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
@@ -1445,19 +1466,19 @@ void stft_wave1024_kernel(
                 pass_a(va);
                 exchange1(va);
                 if (!(ABL & 1024))
-                    rotate_wave_priority(prio_step + 1);
+                    w1024_prio<kPrioPattern>(1, prio_step);
                 if (pipe)
                     lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 pass_a(vbv, share);
                 exchange1(vbv);
                 if (!(ABL & 1024))
-                    rotate_wave_priority(prio_step + 2);
+                    w1024_prio<kPrioPattern>(2, prio_step);
                 pass_bc(va);
                 strip(va, pa);
                 pass_bc(vbv);
                 strip(vbv, pb);
                 if (!(ABL & 1024))
-                    rotate_wave_priority(prio_step + 3);
+                    w1024_prio<kPrioPattern>(3, prio_step);
                 epilogue(va, pa, ta, true, 0);
                 epilogue(vbv, pb, tb, vb, 1);
                 if (OUT == kLogMel) {
@@ -2159,6 +2180,19 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_R_WC
 #define AA_R_WC 0
 #endif
+#ifndef AA_WSMALL_PRIO
+#define AA_WSMALL_PRIO 0     // stft_wave_small_kernel: 0 one rotation step per frame group; ab: level a from the group's top, b behind its exchange
+#endif
+#ifndef AA_W2048_PRIO_MEL
+#define AA_W2048_PRIO_MEL 0  // fused mel rows: 0 the three-level rotation, 1 priority by phase (3 top, 2 behind the exchanges, 1 split, 0 gather)
+#endif
+#ifndef AA_W2048_PRIO
+#define AA_W2048_PRIO 210    // magnitude-type rows: 0 the four-level rotation; abc: priority by phase, the same in every workgroup - level a
+                             // from the chunk top, b behind the first exchanges, c from the split on.  r3: three descending levels
+                             // (210, 310, 320, 321 alike) take 4 % off the 2048 / 512 magnitude launch (77.8 -> 74.6 us; 81.7 -> 78.9 with
+                             // HBM-sourced samples); two levels do nothing; complex rows and the fused mel rows lose with it (6 % at
+                             // log-mel) and keep their rotations; the 1024 kernel (four waves per SIMD) is level with its rotation.
+#endif
 #ifndef AA_R_TWS
 #define AA_R_TWS 0
 #endif
@@ -2203,6 +2237,7 @@ void stft_wave2048_kernel(
     v2f *scr = reinterpret_cast<v2f *>(smem + stage_dwords + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    constexpr bool kPhasePrio = AA_W2048_PRIO != 0 && (OUT == kMag || OUT == kPower || OUT == kLogPower);
     // global stores a wave issues for its ONE row of a full 4-frame chunk (see stft_wave1024_kernel)
     constexpr int kRowStoresPerChunk = OUT == kComplex ? (WIDE ? 9 : 17)      // 8 dwordx4 + 1 dwordx2 | 17 dwordx2
                                        : WIDE          ? 5                    // 4 dwordx4 + head / tail dword
@@ -2316,7 +2351,11 @@ void stft_wave2048_kernel(
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int prio_step = (int)(blockIdx.x >> 8) + (MEL ? 3 : 2) * (c - c0);   // see rotate_wave_priority[3]
-        if (MEL)
+        if (kPhasePrio)
+            __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 100) % 10);
+        else if (AA_W2048_PRIO_MEL && MEL)
+            __builtin_amdgcn_s_setprio(3);
+        else if (MEL)
             rotate_wave_priority3(prio_step);
         else
             rotate_wave_priority(prio_step);
@@ -2414,7 +2453,11 @@ void stft_wave2048_kernel(
             fft512_exchange1(e, e1w, e1r);
             fft512_pass_a(o, twA);
             fft512_exchange1(o, e1w, e1r);
-            if (MEL)
+            if (kPhasePrio)
+                __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 10) % 10);
+            else if (AA_W2048_PRIO_MEL && MEL)
+                __builtin_amdgcn_s_setprio(2);
+            else if (MEL)
                 rotate_wave_priority3(prio_step + 1);
             else
                 rotate_wave_priority(prio_step + 1);
@@ -2462,6 +2505,10 @@ void stft_wave2048_kernel(
             for (int j = 0; j < 8; ++j)
                 prt[j] = scr[512 - (lane + 64 * j)];
             __builtin_amdgcn_wave_barrier();
+            if (kPhasePrio)
+                __builtin_amdgcn_s_setprio(AA_W2048_PRIO % 10);
+            if (AA_W2048_PRIO_MEL && MEL)
+                __builtin_amdgcn_s_setprio(1);
             if (STREAM)
                 asm volatile("" : "+v"(lane));
 
@@ -2559,7 +2606,10 @@ void stft_wave2048_kernel(
                     if (lane == 0)
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
-                    rotate_wave_priority3(prio_step + 2);
+                    if (AA_W2048_PRIO_MEL)
+                        __builtin_amdgcn_s_setprio(0);
+                    else
+                        rotate_wave_priority3(prio_step + 2);
                     if (OUT == kLogMelR)
                         mel_reduce_streamed<(NS > 0 ? NS : 2)>(lds_addr(lrow), mel_par, sch, melstage);
                     else
@@ -2758,7 +2808,10 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         const unsigned wrap7 = rotA ? (unsigned)(8 * (N / 2)) : 0u;
 
         for (int g = wave; FPW * g < nf; g += 4) {
-            rotate_wave_priority(prio_step++);
+            if (AA_WSMALL_PRIO)
+                __builtin_amdgcn_s_setprio((AA_WSMALL_PRIO / 10) % 10);
+            else
+                rotate_wave_priority(prio_step++);
             const int t = FPW * g + fqA;               // this lane's frame within the chunk
             const int nvalid = nf - FPW * g < FPW ? nf - FPW * g : FPW;
             // a lane of a frame past the end reads the last valid frame instead (stays in the
@@ -2798,6 +2851,8 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             }
             // ---- E: q' <-> k1 through LDS (addresses of stft_wave1024_kernel's E1) ----
             fft512_exchange1(v, e_wr, e_rd);
+            if (AA_WSMALL_PRIO)
+                __builtin_amdgcn_s_setprio(AA_WSMALL_PRIO % 10);
             // ---- pass C: lane l of its frame ends with Z[l + LPF mu] in register mu ----
             pk_dft8(v);
 
