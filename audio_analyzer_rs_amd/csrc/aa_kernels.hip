@@ -2352,7 +2352,7 @@ void stft_wave2048_kernel(
         __builtin_amdgcn_s_barrier();
         const int prio_step = (int)(blockIdx.x >> 8) + (MEL ? 3 : 2) * (c - c0);   // see rotate_wave_priority[3]
         if (kPhasePrio)
-            __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 100) % 10);
+            __builtin_amdgcn_s_setprio(AA_W2048_PRIO >= 1000 ? (AA_W2048_PRIO / 1000) % 10 : (AA_W2048_PRIO / 100) % 10);
         else if (AA_W2048_PRIO_MEL && MEL)
             __builtin_amdgcn_s_setprio(3);
         else if (MEL)
@@ -2451,6 +2451,8 @@ void stft_wave2048_kernel(
             const v4f *e1r = STREAM ? reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3)) : e1_rd;
             fft512_pass_a(e, twA);
             fft512_exchange1(e, e1w, e1r);
+            if (kPhasePrio && AA_W2048_PRIO >= 1000)
+                __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 100) % 10);
             fft512_pass_a(o, twA);
             fft512_exchange1(o, e1w, e1r);
             if (kPhasePrio)
