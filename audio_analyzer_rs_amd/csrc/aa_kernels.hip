@@ -2180,6 +2180,9 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_R_WC
 #define AA_R_WC 0
 #endif
+#ifndef AA_W2048_DMA_LATE
+#define AA_W2048_DMA_LATE 1  // r3: -0.4 % (75.0 -> 74.7 us), same order of the vector-memory operations (DMA, then the chunk's stores)
+#endif
 #ifndef AA_WSMALL_PRIO
 #define AA_WSMALL_PRIO 0     // stft_wave_small_kernel: 0 one rotation step per frame group; ab: level a from the group's top, b behind its exchange
 #endif
@@ -2379,8 +2382,14 @@ void stft_wave2048_kernel(
                 twA4[3] = gload4_issue<3072>(ab4, voff);
             }
         }
+        // AA_W2048_DMA_LATE (RING == 2, magnitude / complex rows): the DMA of the chunk after next is issued BEHIND the
+        // frame reads of this chunk (its scalar address loop then runs under their LDS round trip) instead of in front
+        constexpr bool kDmaLate = AA_W2048_DMA_LATE && RING == 2 && !MEL && !STREAM;
+        bool dma_due = false;
         if (RING) {
-            if (!(RING == 2 && MEL))                     // (those: behind the gather)
+            if (kDmaLate && wave < nf)
+                dma_due = true;
+            else if (!(RING == 2 && MEL))                     // (those: behind the gather)
                 dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
         } else if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
@@ -2404,6 +2413,10 @@ void stft_wave2048_kernel(
                 for (int j = 0; j < 8; ++j) {
                     const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
                     raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
+                }
+                if (kDmaLate && dma_due) {
+                    dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
+                    dma_due = false;
                 }
                 if (!STREAM) {
                 } else if (n_dma == 2)
