@@ -806,6 +806,12 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_SHARE
 #define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
 #endif
+#ifndef AA_V_WAIT_A
+#define AA_V_WAIT_A 0      // counted LDS wait: pass A of frame a starts when ITS eight reads are in, frame b's land under it
+#endif
+#ifndef AA_V_DMA_LATE
+#define AA_V_DMA_LATE 1    // PAIR: the next chunk's LDS-DMA issued behind the frame reads of this chunk (r3: -0.8 %, 69.2 -> 68.65 us)
+#endif
 #ifndef AA_V_PIPE
 #define AA_V_PIPE 0        // PAIR: the frames of chunk c + 1 are read from LDS while the rows of chunk c are staged out
 #endif
@@ -1055,6 +1061,7 @@ void stft_wave1024_kernel(
     static_assert(!PIPE || (PAIR && !AA_V_ILV && !(ABL & 8)), "PIPE is a variant of the adjacent-frame magnitude path");
     constexpr bool pipe = PIPE;                              // (the launcher instantiates it for 8 frames per chunk only)
     v2f va[8], vbv[8];
+    bool dma_due = false;
     if (pipe && c0 < c1) {
         wait_vmcnt_le<0>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1089,9 +1096,17 @@ void stft_wave1024_kernel(
         __builtin_amdgcn_s_barrier();
         if (!(ABL & 1024))
             w1024_prio<kPrioPattern>(0, prio_step);
+        // AA_V_DMA_LATE: the LDS-DMA of the next chunk is issued BEHIND this chunk's frame reads (its scalar address
+        // loop then runs under their LDS round trip); the order of the vector-memory operations - DMA, then the
+        // chunk's stores - is the same.  Waves without a frame (ragged last chunk only) issue it here.
+        dma_due = false;
         if (c + cstep < c1 && !(ABL & 8)) {
-            const int nleft = frames_left - frames_step;
-            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+            if (AA_V_DMA_LATE && frames_per_wg == 8 && 2 * wave < nf && PAIR)
+                dma_due = true;
+            else {
+                const int nleft = frames_left - frames_step;
+                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+            }
         }
         } else if (!(ABL & 1024))
             w1024_prio<kPrioPattern>(0, prio_step);
@@ -1446,8 +1461,21 @@ void stft_wave1024_kernel(
                 } else if (!share) {
                     read_frame(ta, va);
                     read_frame(tb, vbv);
-                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                    if (dma_due) {
+                        const int nleft = frames_left - frames_step;
+                        stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+                        dma_due = false;
+                    }
+                    if (AA_V_WAIT_A) {
+                        // frame a alone (LDS returns in order: at most frame b's eight reads still in flight);
+                        // frame b is waited for in front of its own pass A
+                        asm volatile("s_waitcnt lgkmcnt(8)"
+                                     : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7])
+                                     :: "memory");
+                    } else {
+                        lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                        lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+                    }
                 }
                 if (share)
                     read_frame(ta, va);
@@ -1467,7 +1495,7 @@ void stft_wave1024_kernel(
                 exchange1(va);
                 if (!(ABL & 1024))
                     w1024_prio<kPrioPattern>(1, prio_step);
-                if (pipe)
+                if (pipe || (AA_V_WAIT_A && !share))
                     lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 pass_a(vbv, share);
                 exchange1(vbv);
@@ -2183,6 +2211,9 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_W2048_DMA_LATE
 #define AA_W2048_DMA_LATE 1  // r3: -0.4 % (75.0 -> 74.7 us), same order of the vector-memory operations (DMA, then the chunk's stores)
 #endif
+#ifndef AA_WSMALL_DMA_LATE
+#define AA_WSMALL_DMA_LATE 0
+#endif
 #ifndef AA_WSMALL_PRIO
 #define AA_WSMALL_PRIO 0     // stft_wave_small_kernel: 0 one rotation step per frame group; ab: level a from the group's top, b behind its exchange
 #endif
@@ -2813,9 +2844,16 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         __builtin_amdgcn_s_barrier();
         int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority; + 1 per group
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
+        // AA_WSMALL_DMA_LATE: the next chunk's LDS-DMA behind the frame reads of the wave's first group (as in stft_wave1024_kernel;
+        // measured +-0 here - 68.4 against 68.7 us at 256 / 64 - and left off)
+        bool dma_due = false;
         if (c + 1 < c1) {
-            const int nleft = frames_left - frames_per_wg;
-            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+            if (AA_WSMALL_DMA_LATE && FPW * wave < nf)
+                dma_due = true;
+            else {
+                const int nleft = frames_left - frames_per_wg;
+                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+            }
         }
         // register j <- block (j + rotA) mod 8: blocks are N / 2 bytes apart; one base for j = 0..6,
         // the wrapped one for j = 7
@@ -2838,6 +2876,11 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             v[2] = small_frame_read<N, 256>(fr); v[3] = small_frame_read<N, 384>(fr);
             v[4] = small_frame_read<N, 512>(fr); v[5] = small_frame_read<N, 640>(fr);
             v[6] = small_frame_read<N, 768>(fr); v[7] = small_frame_read<N, 896>(fr - wrap7);
+            if (dma_due) {
+                const int nleft = frames_left - frames_per_wg;
+                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+                dma_due = false;
+            }
             lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
