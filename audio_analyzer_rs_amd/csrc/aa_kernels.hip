@@ -810,7 +810,8 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #define AA_V_WAIT_A 0      // counted LDS wait: pass A of frame a starts when ITS eight reads are in, frame b's land under it
 #endif
 #ifndef AA_V_DMA_LATE
-#define AA_V_DMA_LATE 1    // PAIR: the next chunk's LDS-DMA issued behind the frame reads of this chunk (r3: -0.8 %, 69.2 -> 68.65 us)
+#define AA_V_DMA_LATE 1    // magnitude-type and log-mel rows: the next chunk's LDS-DMA issued behind the frame reads of this chunk (r3: -0.8 %,
+                           // 69.2 -> 68.65 us; log-mel -0.7 %); 2: every output kind
 #endif
 #ifndef AA_V_PIPE
 #define AA_V_PIPE 0        // PAIR: the frames of chunk c + 1 are read from LDS while the rows of chunk c are staged out
@@ -1101,7 +1102,8 @@ void stft_wave1024_kernel(
         // chunk's stores - is the same.  Waves without a frame (ragged last chunk only) issue it here.
         dma_due = false;
         if (c + cstep < c1 && !(ABL & 8)) {
-            if (AA_V_DMA_LATE && frames_per_wg == 8 && 2 * wave < nf && PAIR)
+            if (AA_V_DMA_LATE && frames_per_wg == 8 && (PAIR ? 2 * wave : wave) < nf &&
+                (PAIR || OUT == kLogMel || OUT == kLogMelR || AA_V_DMA_LATE == 2))   // (MFCC +0.8 %, complex rows +0.4 % with it: left at the top)
                 dma_due = true;
             else {
                 const int nleft = frames_left - frames_step;
@@ -2208,6 +2210,9 @@ constexpr int kRingBlocks = 22;
 #ifndef AA_R_WC
 #define AA_R_WC 0
 #endif
+#ifndef AA_W2048_PIPE
+#define AA_W2048_PIPE 0      // RING == 2 magnitude-type rows: the frame of chunk c + 1 is read from the ring while the row of chunk c is staged out
+#endif
 #ifndef AA_W2048_DMA_LATE
 #define AA_W2048_DMA_LATE 1  // r3: -0.4 % (75.0 -> 74.7 us), same order of the vector-memory operations (DMA, then the chunk's stores)
 #endif
@@ -2272,6 +2277,9 @@ void stft_wave2048_kernel(
     constexpr int NB = 1025;
     constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
     constexpr bool kPhasePrio = AA_W2048_PRIO != 0 && (OUT == kMag || OUT == kPower || OUT == kLogPower);
+    // software pipeline over the chunks (see the hook in the row staging below): the chunk-top wait and barrier move to the
+    // tail of the previous chunk's body, in front of the frame reads of the next one
+    constexpr bool kPipe = AA_W2048_PIPE && RING == 2 && !MEL && RING != 1 && WIDE && OUT != kComplex;
     // global stores a wave issues for its ONE row of a full 4-frame chunk (see stft_wave1024_kernel)
     constexpr int kRowStoresPerChunk = OUT == kComplex ? (WIDE ? 9 : 17)      // 8 dwordx4 + 1 dwordx2 | 17 dwordx2
                                        : WIDE          ? 5                    // 4 dwordx4 + head / tail dword
@@ -2359,8 +2367,21 @@ void stft_wave2048_kernel(
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
 
     int dma_prev = 0;                                   // RING == 2: DMA instructions of the last round
+    v4f raw[8];                                         // RING: the wave's frame as it comes from the ring (kPipe: loop carried)
+    if (kPipe && c0 < c1) {
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                  // the first two chunks have landed
+        const int s0 = (2 * wave) % RB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                   // (a wave without a frame reads too: no branch around the registers)
+            const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
+            raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane0];
+        }
+    }
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
+        if (!kPipe) {
         // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
         // row in the previous (full) chunk, after issuing this chunk's DMA loads
         if (c == c0 || frames_per_wg != 4)
@@ -2384,6 +2405,7 @@ void stft_wave2048_kernel(
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        }
         const int prio_step = (int)(blockIdx.x >> 8) + (MEL ? 3 : 2) * (c - c0);   // see rotate_wave_priority[3]
         if (kPhasePrio)
             __builtin_amdgcn_s_setprio(AA_W2048_PRIO >= 1000 ? (AA_W2048_PRIO / 1000) % 10 : (AA_W2048_PRIO / 100) % 10);
@@ -2418,7 +2440,9 @@ void stft_wave2048_kernel(
         constexpr bool kDmaLate = AA_W2048_DMA_LATE && RING == 2 && !MEL && !STREAM;
         bool dma_due = false;
         if (RING) {
-            if (kDmaLate && wave < nf)
+            if (kPipe)
+                dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));     // (the frame is in registers already)
+            else if (kDmaLate && wave < nf)
                 dma_due = true;
             else if (!(RING == 2 && MEL))                     // (those: behind the gather)
                 dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
@@ -2439,11 +2463,12 @@ void stft_wave2048_kernel(
             if (RING) {
                 // frame t starts at block 8 (c - c0) + 2 t; read j is block + j
                 const int s0 = (8 * (c - c0) + 2 * t) % RB;
-                v4f raw[8];
+                if (!kPipe) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
-                    raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
+                    for (int j = 0; j < 8; ++j) {
+                        const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
+                        raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
+                    }
                 }
                 if (kDmaLate && dma_due) {
                     dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
@@ -2672,6 +2697,27 @@ void stft_wave2048_kernel(
                     if (lane == 0)
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
+                    if (kPipe) {
+                        // .. DMA(c + 1) | stores(c - 1) | DMA(c + 2) .. : leave the row stores of the previous chunk and
+                        // the DMA instructions of this chunk's round in flight (the first chunk: chunk c0 + 1 landed in
+                        // the prologue); the barrier also says that every wave is done with the frames of chunk c
+                        if (c + 1 < c1) {
+                            if (c == c0) {
+                            } else if (dma_prev == 2)
+                                wait_vmcnt_le<kRowStoresPerChunk + 2>();
+                            else if (dma_prev == 1)
+                                wait_vmcnt_le<kRowStoresPerChunk + 1>();
+                            else
+                                wait_vmcnt_le<kRowStoresPerChunk>();
+                            __builtin_amdgcn_s_barrier();
+                        }
+                        const int s1 = (8 * (c - c0 + 1) + 2 * t) % RB;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int sj = s1 + j < RB ? s1 + j : s1 + j - RB;
+                            raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
+                        }
+                    }
                     const float *lw = reinterpret_cast<const float *>(scr);
                     float *gw = row - sh;
                     // window floats 4..1023 as 4 dwordx4 pieces (the last one 63 lanes), head
