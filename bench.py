@@ -330,7 +330,53 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     bl = HOP * 4 + n_mels * 4
     out["logmel_1024_256"] = {"kernel": lplan.kernel, "frames": nf, "ms": r4(ms), "B_per_frame": bl,
                               "frac": r4(bl * nf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+    del mbuf, lbuf
+    out["next_rows"] = next_rows(aa, torch, dev, timer, xd)
     return out
+
+
+def next_rows(aa, torch, dev, timer, xd):
+    """SURVEY.md section 8(f) rows behind the STFT, timed on the 10-min corpus cut into independent streams (their
+    recurrences run over frames: one wave / one lane per bin per stream, so the parallelism is across streams):
+    onset flux + gates on the 256/64 magnitudes (onset.rs:261-371), tuner noise floor + pitch extraction on the
+    2048/512 magnitudes (stft.rs:326-367, 443-620).  Parity of each is the GPU test suite's business."""
+    st = timer.stream.cuda_stream
+    rec = {}
+    try:
+        mags = aa.Stft(256, 64, output="mag")(xd)
+        torch.cuda.synchronize(dev)
+        nfo, nbo = mags.shape
+        gf = torch.full((nfo,), float(10.0 ** (-60 / 20.0) * nbo / 2.0), device=dev)
+        for ns in (1024,):
+            offs = torch.tensor(np.linspace(0, nfo, ns + 1).astype(np.int64), device=dev)
+            flux, energy = aa.onset_flux(mags, offsets=offs, stream=st)
+            torch.cuda.synchronize(dev)
+
+            def onset_chain():
+                f, e = aa.onset_flux(mags, offsets=offs, stream=st)
+                aa.onset_gates(mags, f, e, gf, offsets=offs, stream=st)
+
+            ms, _ = timer.time(onset_chain, 5, 2)
+            rec["onset_flux_gates_256_64"] = {"frames": nfo, "streams": ns, "ms": r4(ms),
+                                              "frames_per_s": r4(nfo / (ms * 1e-3)), "B_per_frame": 2 * nbo * 4 + 41}
+        del mags, flux, energy, gf
+        mags = aa.Stft(2048, 512, output="mag")(xd)
+        torch.cuda.synchronize(dev)
+        nft, nbt = mags.shape
+        gft = torch.full((nft,), 0.5, device=dev)
+        offs = torch.tensor(np.linspace(0, nft, 257).astype(np.int64), device=dev)
+        eff, _ = aa.tuner_floor(mags, gft, offsets=offs, stream=st)
+
+        def tuner_chain():
+            e, _ = aa.tuner_floor(mags, gft, offsets=offs, stream=st)
+            aa.tuner_pitches(mags, e, SR / 2048, stream=st)
+
+        ms, _ = timer.time(tuner_chain, 5, 2)
+        rec["tuner_floor_pitches_2048_512"] = {"frames": nft, "streams": 256, "ms": r4(ms),
+                                               "frames_per_s": r4(nft / (ms * 1e-3)), "B_per_frame": 3 * nbt * 4 + 68}
+    except Exception as ex:                                   # noqa: BLE001 (reported, never fatal for the headline line)
+        rec["error"] = f"{type(ex).__name__}: {ex}"
+    return rec
 
 
 # --------------------------------------------------------------------------- N == 1 --
