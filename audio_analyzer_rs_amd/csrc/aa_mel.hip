@@ -388,6 +388,10 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
 // relative and a decision can flip only on an exact tie.  Equal scores keep bin order (the
 // reference's sort_unstable_by leaves that unspecified).
 constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
+// PREF (n_bins <= 64 * 17, the tuner's 1025 included): the frame's two rows come in as 2 x 17 loads issued back to back into
+// registers - the rows of the block's NEXT frame while the current one is scored - instead of a loop of dependent
+// load -> LDS store pairs (17 serialised global round trips per frame: two thirds of the kernel's wave cycles were that wait).
+template <bool PREF>
 __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     const float *__restrict__ mags, const float *__restrict__ eff_floor, int64_t n_frames, int n_bins,
     float bin_width, float min_freq, float max_freq, int min_bin, int max_bin, int max_peaks,
@@ -399,18 +403,49 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     const int nbp = (n_bins + 3) & ~3;
     float *m = pit_lds, *nf = m + nbp;
     float *score = nf + nbp, *frac = score + max_peaks;        // per peak ordinal
-    float *kfrac = frac + max_peaks, *kscore = kfrac + max_peaks;   // kept (unsuppressed) candidates
-    float *sfrac = kscore + max_peaks, *sscore = sfrac + max_peaks; // sorted by score
-    int *peak_bin = reinterpret_cast<int *>(sscore + max_peaks), *cand = peak_bin + max_peaks;
+    // r3: the later stages reuse dead areas (every stage ends in a workgroup barrier) - 25.7 KB instead of 42 KB per
+    // block, six resident blocks per CU instead of three: the kept candidates land on the frame's rows (last read by
+    // the scoring), the sorted ones on score / frac (last read when the kept ones were picked)
+    float *kfrac = m, *kscore = nf;                            // kept (unsuppressed) candidates
+    float *sfrac = score, *sscore = frac;                      // sorted by score
+    int *peak_bin = reinterpret_cast<int *>(frac + max_peaks), *cand = peak_bin + max_peaks;
     unsigned char *is_peak = reinterpret_cast<unsigned char *>(cand + max_peaks);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int half_size = n_bins;
+    constexpr int kIt = 17;
+    float rm[kIt], rn[kIt];
+    auto row_loads = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int k = lane + 64 * i;
+            if (k < n_bins) {
+                rm[i] = mags[t * n_bins + k];
+                rn[i] = eff_floor[t * n_bins + k];
+            }
+        }
+    };
+    if (PREF && (int64_t)blockIdx.x < n_frames)
+        row_loads(blockIdx.x);
     for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {
         __syncthreads();
-        for (int k = lane; k < n_bins; k += 64) {
-            m[k] = mags[t * n_bins + k];
-            nf[k] = eff_floor[t * n_bins + k];
-            is_peak[k] = 0;
+        if (PREF) {
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                const int k = lane + 64 * i;
+                if (k < n_bins) {
+                    m[k] = rm[i];
+                    nf[k] = rn[i];
+                    is_peak[k] = 0;
+                }
+            }
+            if (t + gridDim.x < n_frames)
+                row_loads(t + gridDim.x);
+        } else {
+            for (int k = lane; k < n_bins; k += 64) {
+                m[k] = mags[t * n_bins + k];
+                nf[k] = eff_floor[t * n_bins + k];
+                is_peak[k] = 0;
+            }
         }
         __syncthreads();
         // ---- peaks, compacted in bin order ----
@@ -757,13 +792,18 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
         max_bin = n_bins - 2;
     const int max_peaks = n_bins;                    // plateaus can make neighbouring bins peaks
     const int nbp = (n_bins + 3) & ~3;
-    const size_t lds = sizeof(float) * (size_t)(2 * nbp + 8 * max_peaks) + (size_t)nbp;
+    const size_t lds = sizeof(float) * (size_t)(2 * nbp + 4 * max_peaks) + (size_t)nbp;
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
     int64_t blocks = n_frames < 16384 ? n_frames : 16384;
-    hipLaunchKernelGGL(tuner_pitches_kernel, dim3((unsigned)blocks), dim3(64), lds, stream, mags, eff_floor,
-                       n_frames, n_bins, bin_width, min_freq, max_freq, min_bin, max_bin, max_peaks, out_freq,
-                       out_score, out_count);
+    if (n_bins <= 64 * 17)
+        hipLaunchKernelGGL(tuner_pitches_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, stream, mags, eff_floor,
+                           n_frames, n_bins, bin_width, min_freq, max_freq, min_bin, max_bin, max_peaks, out_freq,
+                           out_score, out_count);
+    else
+        hipLaunchKernelGGL(tuner_pitches_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, stream, mags, eff_floor,
+                           n_frames, n_bins, bin_width, min_freq, max_freq, min_bin, max_bin, max_peaks, out_freq,
+                           out_score, out_count);
     return hipGetLastError();
 }
 
