@@ -102,6 +102,11 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
                            const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0,
                            const Channels *channels = nullptr);
 
+// kMfccR of launch_wave1024, defined in aa_kernels_mfcc.hip (arguments already validated by launch_wave1024)
+hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+                                int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
+                                const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch);
+
 // ---- two frames per wave, n_fft 1024 at hop 256 (the BASELINE geometry) -----------------------
 // stft_wave1024x2_kernel: the two adjacent frames of a wave sit side by side in its half-waves, 16
 // complex points per lane, 512 = 16 x 16 x 2: two radix-16 passes in registers, ONE exchange through

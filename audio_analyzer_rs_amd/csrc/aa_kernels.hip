@@ -3612,6 +3612,18 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
     return hipGetLastError();
 }
 
+#ifdef AA_TU_MFCC
+// aa_kernels_mfcc.hip: this file once more, for the fused MFCC instantiation of stft_wave1024_kernel alone, compiled with
+// -mllvm -amdgpu-sched-strategy=max-ilp (r3: -2.5 % for that kernel, 94.9 -> 92.6 us; as a flag of the whole library it makes nine
+// fallback instantiations of the 2048 kernel spill and costs the 256 kernel a wave per SIMD, csrc/Makefile).
+hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+                                int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
+                                const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch)
+{
+    return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream,
+                                        mel_par, sch, dct_tab, n_mfcc, ch);
+}
+#else
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched,
@@ -3645,8 +3657,9 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
         return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kLogMelR:
         return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
-    case kMfccR:
-        return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, dct_tab, n_mfcc, ch);
+    case kMfccR:   // built in a translation unit of its own (aa_kernels_mfcc.hip: another scheduler strategy)
+        return launch_wave1024_mfcc(x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch,
+                                    dct_tab, n_mfcc, ch);
     default:
         return hipErrorInvalidValue;
     }
@@ -3933,6 +3946,7 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
     return hipGetLastError();
 }
 
+#endif  // AA_TU_MFCC
 #endif  // AA_ABLATE
 
 }  // namespace aa

@@ -13,6 +13,6 @@ while [ $# -ge 2 ]; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $DEFS -Rpass-analysis=kernel-resource-usage -c -o $REPO/tools/bin/k_$NAME.o $C/aa_kernels.hip 2> $REPO/tools/bin/k_$NAME.remarks &&
     echo "$NAME: $(grep -A12 "${SHOW:-wave1024x2_kernelILi1}" $REPO/tools/bin/k_$NAME.remarks | grep -E " VGPRs:|ScratchSize" | sed 's/.*remark: *//; s/ \[-R.*//' | tr '\n' ' ')" &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $REPO/tools/bin/lib_$NAME.so $REPO/tools/bin/k_$NAME.o \
-        $C/build/aa_mel.o $C/build/aa_abi.o $C/build/aa_theory.o $C/build/aa_comm.o -ldl && echo built lib_$NAME.so ) &
+        $C/build/aa_kernels_mfcc.o $C/build/aa_mel.o $C/build/aa_abi.o $C/build/aa_theory.o $C/build/aa_comm.o -ldl && echo built lib_$NAME.so ) &
 done
 wait

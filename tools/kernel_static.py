@@ -16,9 +16,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-strict-aliasi
 WAVE = re.compile(r"stft_wave(1024x2|1024|2048|_small)_kernel")
 
 
-def compile_asm(out_s):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *FLAGS, "-S", "--cuda-device-only",
-           "-Rpass-analysis=kernel-resource-usage", "-o", out_s, os.path.join(CSRC, "aa_kernels.hip")]
+def compile_asm(out_s, src="aa_kernels.hip", extra=()):
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *FLAGS, *extra, "-S", "--cuda-device-only",
+           "-Rpass-analysis=kernel-resource-usage", "-o", out_s, os.path.join(CSRC, src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(r.stderr[-2000:])
@@ -35,6 +35,10 @@ def facts():
         s_path = os.path.join(td, "k.s")
         remarks = compile_asm(s_path)
         text = open(s_path).read()
+        # the fused MFCC kernel is a translation unit of its own, with its own scheduler strategy (csrc/Makefile)
+        m_path = os.path.join(td, "m.s")
+        remarks += compile_asm(m_path, "aa_kernels_mfcc.hip", ("-mllvm", "-amdgpu-sched-strategy=max-ilp"))
+        text += open(m_path).read()
     res = {}
     cur = None
     for line in remarks.splitlines():
