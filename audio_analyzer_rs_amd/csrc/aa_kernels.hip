@@ -806,6 +806,9 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
 #ifndef AA_V_SHARE
 #define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
 #endif
+#ifndef AA_V_HALO_COPY
+#define AA_V_HALO_COPY 0   // the 1024 - hop samples two consecutive chunks share: copied inside LDS instead of fetched by the next chunk's DMA again
+#endif
 #ifndef AA_V_WAIT_A
 #define AA_V_WAIT_A 0      // counted LDS wait: pass A of frame a starts when ITS eight reads are in, frame b's land under it
 #endif
@@ -999,14 +1002,25 @@ void stft_wave1024_kernel(
 
     // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
     // (wave w moves the 1 KiB pieces w, w+4, ..)
-    auto stage = [&](const float *src, int nfc, int which) {
+    // skip4 (AA_V_HALO_COPY): the first skip4 float4 of the span are NOT fetched - they are the 1024 - hop samples the next chunk
+    // shares with this one and are copied from this chunk's buffer inside LDS (halo_copy) instead of read from L2 again
+    auto stage = [&](const float *src, int nfc, int which, int skip4 = 0) {
         const int span4 = ((nfc - 1) * hop + 1024) >> 2;
         float *dst = smem + which * max_span;
-        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+        for (int qb = skip4 + wave * 64; qb < span4; qb += kWave1024Threads) {
             const int q = qb + lane;
             if (q < span4)
                 lds_dma_16(src + 4 * q, dst + 4 * qb);
         }
+    };
+    const int halo4 = AA_V_HALO_COPY && hop < 1024 ? (1024 - hop) >> 2 : 0;      // float4 shared by consecutive chunks
+    // behind the chunk-top barrier of chunk c (its samples have landed; every wave is done with the other buffer):
+    // buffer[other][0 .. halo) = buffer[cur][frames_per_wg hop ..), a quarter per wave
+    auto halo_copy = [&](int cur_buf) {
+        const v4f *from = reinterpret_cast<const v4f *>(smem + cur_buf * max_span + frames_per_wg * hop);
+        v4f *to = reinterpret_cast<v4f *>(smem + (cur_buf ^ 1) * max_span);
+        for (int q = tid; q < halo4; q += kWave1024Threads)
+            to[q] = from[q];
     };
 
     if (c0 < c1)
@@ -1101,13 +1115,15 @@ void stft_wave1024_kernel(
         // loop then runs under their LDS round trip); the order of the vector-memory operations - DMA, then the
         // chunk's stores - is the same.  Waves without a frame (ragged last chunk only) issue it here.
         dma_due = false;
+        if (c + cstep < c1 && !(ABL & 8) && halo4 && cstep == 1)
+            halo_copy(cur);
         if (c + cstep < c1 && !(ABL & 8)) {
             if (AA_V_DMA_LATE && frames_per_wg == 8 && (PAIR ? 2 * wave : wave) < nf &&
                 (PAIR || OUT == kLogMel || OUT == kLogMelR || AA_V_DMA_LATE == 2))   // (MFCC +0.8 %, complex rows +0.4 % with it: left at the top)
                 dma_due = true;
             else {
                 const int nleft = frames_left - frames_step;
-                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1, cstep == 1 ? halo4 : 0);
             }
         }
         } else if (!(ABL & 1024))
@@ -1465,7 +1481,7 @@ void stft_wave1024_kernel(
                     read_frame(tb, vbv);
                     if (dma_due) {
                         const int nleft = frames_left - frames_step;
-                        stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+                        stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1, cstep == 1 ? halo4 : 0);
                         dma_due = false;
                     }
                     if (AA_V_WAIT_A) {
