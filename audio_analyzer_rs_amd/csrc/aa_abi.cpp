@@ -40,20 +40,7 @@ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
-            ok = true;
-    }
-    ~DeviceGuard()
-    {
-        if (ok && prev >= 0)
-            (void)hipSetDevice(prev);
-    }
-};
+using aa::DeviceGuard;
 
 // Twiddle tables shared by the generic kernels: W_m^q (q < m/2 for powers of two,
 // q < m otherwise) and the split table W_n^k, k <= m/2.  f64 evaluation, f32 storage.

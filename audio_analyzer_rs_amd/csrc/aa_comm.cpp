@@ -144,25 +144,11 @@ struct GroupScope {
     }
 };
 
-// The communicator's device is selected for the duration of every call that takes a comm: a host
-// thread that never called hipSetDevice sits on device 0, and hipMemcpyAsync / hipStreamSynchronize /
-// ncclSend / ncclRecv act on the CURRENT device (as the plan entry points do in aa_abi.cpp).
-struct CommDeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit CommDeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
-            ok = true;
-    }
-    ~CommDeviceGuard()
-    {
-        if (ok && prev >= 0)
-            (void)hipSetDevice(prev);
-    }
-};
+// The communicator's device is selected for the duration of every call that takes a comm (aa::DeviceGuard): a host
+// thread that never called hipSetDevice sits on device 0, and hipMemcpyAsync / hipStreamSynchronize / ncclSend /
+// ncclRecv act on the CURRENT device.
 #define COMM_DEVICE(c, what)                                                                   \
-    CommDeviceGuard dev_guard_((c)->device);                                                   \
+    aa::DeviceGuard dev_guard_((c)->device);                                                   \
     if (!dev_guard_.ok)                                                                        \
     return fail(AA_ERR_HIP, what ": cannot select device %d", (c)->device)
 
@@ -244,7 +230,7 @@ int aa_comm_destroy(aa_comm *c)
     if (!c)
         return AA_OK;
     int rc = AA_OK;
-    CommDeviceGuard g(c->device);                            // best effort: the handle is released either way
+    aa::DeviceGuard g(c->device);                            // best effort: the handle is released either way
     if (c->comm && g_rccl.CommDestroy) {
         ncclResult_t r = g_rccl.CommDestroy(c->comm);
         if (r != 0)

@@ -10,6 +10,25 @@ namespace aa {
 // Sets the calling thread's aa_last_error() text and returns `code` (defined in aa_abi.cpp).
 int abi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Selects device `dev` for the lifetime of the guard and restores the previous one: every entry point that takes a
+// plan or a communicator acts on ITS device, whatever the calling thread had selected (a new host thread sits on 0).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
+            ok = true;
+    }
+    ~DeviceGuard()
+    {
+        if (ok && prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
 // the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
 // kMfccR: kLogMelR + the DCT-II fused behind it (1024 kernel only): the log-mel rows of 16 frames stay
