@@ -421,6 +421,173 @@ bool build_mel_streamed(const std::vector<double> &w, int nb, int n_mels, std::v
     return true;
 }
 
+// kLogMelM / kMfccM (aa_internal.hpp, "band-blocked mel contraction"): the program of the four waves of a
+// workgroup.  The filters are taken in quads of 4 consecutive mels; quad q touches the 4-bin pieces
+// [c_lo, c_hi) of a power row (the last piece of a row - bin nb - 1 = Nyquist and three floats the kernel keeps
+// at zero behind it - is a piece like any other).  With S steps per block a quad needs ceil(pieces / S) blocks
+// (K-slices, consecutive blocks of ONE wave); a wave offers 16 blocks and 8 emission slots (quad slot x 8
+// frames = its 64 lanes).  The quads go to the waves largest first, each to the wave with the most free blocks,
+// and the smallest S that packs wins (fewer steps = fewer MFMAs and fewer resident registers).  The table is
+// verified against the dense filterbank before it is accepted: the kernel's dataflow run on the table must
+// reproduce every f32 weight, each exactly once.
+bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab, aa::MelSched *sch)
+{
+    constexpr int S_MAX = aa::kMelMfmaSteps;
+    if (n_mels < 16 || n_mels > aa::kMelMaxMels || (n_mels & 3) || 4 * nb > 65535)
+        return false;
+    const int nq = n_mels / 4, pieces_max = (nb + 3) / 4;   // pieces 0 .. pieces_max - 1
+    if (4 * pieces_max > aa::kMelMfmaRowB || pieces_max < S_MAX)
+        return false;
+    std::vector<int> c_lo(nq, 0), c_n(nq, 0);
+    for (int q = 0; q < nq; ++q) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            for (int i = 0; i < 4; ++i)
+                if ((float)w[(size_t)(4 * q + i) * nb + k] != 0.0f) {
+                    if (first < 0)
+                        first = k;
+                    last = k;
+                }
+        if (first >= 0) {
+            c_lo[q] = first / 4;
+            c_n[q] = last / 4 + 1 - c_lo[q];
+        }
+    }
+    struct Place { int wave, blk0, slices, slot; };
+    std::vector<Place> place(nq);
+    int S = 0;
+    for (int s_try = 1; s_try <= S_MAX && S == 0; ++s_try) {
+        std::vector<std::pair<int, int>> items;     // (blocks, quad), largest first
+        bool ok = true;
+        for (int q = 0; q < nq; ++q) {
+            const int sl = std::max(1, (c_n[q] + s_try - 1) / s_try);
+            if (sl > 16)
+                ok = false;
+            items.push_back({sl, q});
+        }
+        if (!ok)
+            continue;
+        std::sort(items.begin(), items.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        int free_blocks[4] = {16, 16, 16, 16}, quads[4] = {0, 0, 0, 0};
+        for (const auto &it : items) {
+            int best = -1;
+            for (int wv = 0; wv < 4; ++wv)
+                if (free_blocks[wv] >= it.first && quads[wv] < 8 && (best < 0 || free_blocks[wv] > free_blocks[best]))
+                    best = wv;
+            if (best < 0) {
+                ok = false;
+                break;
+            }
+            place[it.second] = {best, 16 - free_blocks[best], it.first, quads[best]};
+            free_blocks[best] -= it.first;
+            quads[best] += 1;
+        }
+        // every wave must emit something: its row store per chunk is counted by the chunk-top wait
+        for (int wv = 0; wv < 4 && ok; ++wv)
+            if (quads[wv] == 0)
+                ok = false;
+        if (ok)
+            S = s_try;
+    }
+    if (S == 0)
+        return false;
+    *sch = aa::MelSched();
+    sch->n_mels = n_mels;
+    sch->n_steps = S;
+    tab->assign((size_t)aa::kMelMfmaTableDwords, 0.0f);
+    auto wave_tab = [&](int wv) { return tab->data() + (size_t)wv * aa::kMelMfmaWaveDwords; };
+    auto words = [&](int wv) { return reinterpret_cast<uint32_t *>(wave_tab(wv) + (size_t)S_MAX * 64 * 4); };
+    int hmax[4] = {0, 0, 0, 0};
+    for (int q = 0; q < nq; ++q)
+        hmax[place[q].wave] = std::max(hmax[place[q].wave], place[q].slices);
+    for (int wv = 0; wv < 4; ++wv)
+        for (int lane = 0; lane < 64; ++lane)
+            words(wv)[64 + lane] = (uint32_t)hmax[wv] << 24;
+    for (int q = 0; q < nq; ++q) {
+        const Place &pl = place[q];
+        float *T = wave_tab(pl.wave);
+        uint32_t *u = words(pl.wave);
+        for (int f = 0; f < 8; ++f)
+            u[64 + 8 * pl.slot + f] |= (uint32_t)pl.slices | ((uint32_t)pl.blk0 << 5) | ((uint32_t)q << 9);
+        const int per = std::max(1, (c_n[q] + pl.slices - 1) / pl.slices);     // pieces per slice (<= S)
+        for (int h = 0; h < pl.slices; ++h) {
+            const int blk = pl.blk0 + h;
+            const int p0 = c_lo[q] + h * per, p1 = std::min(c_lo[q] + c_n[q], p0 + per);
+            // the block reads (and multiplies: unused steps carry zero weights) kMelMfmaSteps consecutive pieces from
+            // `start`: all of them inside the row
+            const int start = std::max(0, std::min(p0, pieces_max - S_MAX));
+            for (int i = 0; i < 4; ++i) {
+                const int lane = 4 * blk + i;           // A operand: mel 4 q + i; B operand / partial sums: frame j = i
+                u[lane] = 16u * (uint32_t)start;
+                for (int piece = std::max(p0, start); piece < p1; ++piece)
+                    for (int t = 0; t < 4; ++t)
+                        T[((size_t)(piece - start) * 64 + lane) * 4 + t] =
+                            4 * piece + t < nb ? (float)w[(size_t)(4 * q + i) * nb + 4 * piece + t] : 0.0f;
+            }
+        }
+    }
+    // Verification: the kernel's dataflow on the table - per (block, mel i) the weights the MFMAs accumulate over the
+    // S live steps, then the slice sums of every (quad slot, frame) lane - against the dense f32 filterbank.
+    std::vector<char> emitted(n_mels, 0);
+    for (int wv = 0; wv < 4; ++wv) {
+        const float *T = wave_tab(wv);
+        const uint32_t *u = words(wv);
+        std::vector<std::vector<float>> x(64, std::vector<float>(4 * (pieces_max + S_MAX), 0.0f));   // per lane = (block, mel i)
+        for (int lane = 0; lane < 64; ++lane) {
+            const uint32_t off = u[lane];
+            if ((off & 15u) || off / 16 + S_MAX > (uint32_t)pieces_max)
+                return false;
+            for (int s = 0; s < S_MAX; ++s)
+                for (int t = 0; t < 4; ++t) {
+                    const float v = T[((size_t)s * 64 + lane) * 4 + t];
+                    if (v != 0.0f && s >= S)
+                        return false;
+                    x[lane][off / 4 + 4 * s + t] = v;
+                }
+        }
+        for (int slot = 0; slot < 8; ++slot) {
+            const uint32_t em = u[64 + 8 * slot];
+            for (int f = 1; f < 8; ++f)
+                if (u[64 + 8 * slot + f] != em)
+                    return false;
+            if ((int)(em >> 24) != hmax[wv])
+                return false;
+            const int ns = (int)(em & 31u), blk0 = (int)((em >> 5) & 15u), q = (int)((em >> 9) & 31u);
+            if (ns == 0)
+                continue;
+            if (ns > hmax[wv] || blk0 + ns > 16 || q >= nq)
+                return false;
+            for (int i = 0; i < 4; ++i) {
+                const int mel = 4 * q + i;
+                if (emitted[mel])
+                    return false;
+                emitted[mel] = 1;
+                for (int k = 0; k < nb; ++k) {
+                    float sum = 0.0f;
+                    int hits = 0;
+                    for (int h = 0; h < ns; ++h) {
+                        const float v = x[4 * (blk0 + h) + i][k];
+                        sum += v;
+                        hits += v != 0.0f;
+                    }
+                    if (sum != (float)w[(size_t)mel * nb + k] || hits > 1)
+                        return false;
+                }
+                for (int h = 0; h < ns; ++h)                    // nothing past the row's bins
+                    for (size_t k = nb; k < x[4 * (blk0 + h) + i].size(); ++k)
+                        if (x[4 * (blk0 + h) + i][k] != 0.0f)
+                            return false;
+            }
+        }
+    }
+    for (int m = 0; m < n_mels; ++m)
+        if (!emitted[m])
+            return false;
+    return true;
+}
+
 // Per-lane constants of the wave-per-frame 2048 kernel, [kWave2048Rows][64] (row meaning in
 // aa_kernels.hip above stft_wave2048_kernel).
 void build_wave2048_table(const float *window, std::vector<float> *tab)
@@ -616,6 +783,10 @@ struct aa_stft_plan {
     float *d_dct_lane = nullptr;   // its per-lane A-operand table [tile][8][64] float4
     float *d_mel_par = nullptr;    // [kMelParTableDwords], [kMelResidentTableDwords] or [kMelStreamTableDwords]
     aa::MelSched mel_sched;
+    // r4: the mel contraction on v_mfma_f32_4x4x1_16b_f32 (kLogMelM / kMfccM; n_fft 1024, 8 frames per chunk, n_mels % 4 == 0)
+    bool mel_mfma = false, mfcc_mfma = false;
+    float *d_mel_mfma = nullptr;   // [kMelMfmaTableDwords]
+    aa::MelSched mel_mfma_sched;
     // host-execute workspace and the two-stream pipeline used for page-locked host buffers
     hipStream_t pipe_stream[2] = {nullptr, nullptr};
     hipEvent_t pipe_event = nullptr;
@@ -1028,9 +1199,24 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
             // [tile][S][lane][t] = d[c][16 S + 4 kq + t], orthonormal DCT-II as above; zero outside
             // n_mfcc / n_mels / 2.
             const char *no_fuse = std::getenv("AA_MFCC_NO_FUSE");
-            if (ok && p->mel_resident && p->wave1024 && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
-                cfg->n_mels <= aa::kMelMaxMels && cfg->n_mels % 2 == 0 && !(no_fuse && std::atoi(no_fuse) != 0) &&
-                aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384) {
+            const bool fuse_dct = p->wave1024 && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
+                                  cfg->n_mels <= aa::kMelMaxMels && cfg->n_mels % 2 == 0 && !(no_fuse && std::atoi(no_fuse) != 0);
+            // r4: the contraction on the matrix cores (AA_MEL_MFMA=0 keeps the VALU gather for A/B runs)
+            const char *no_mfma = std::getenv("AA_MEL_MFMA");
+            if (p->wave1024 && p->frames_per_wg == 8 && !(no_mfma && std::atoi(no_mfma) == 0) &&
+                aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, cfg->output == AA_OUT_MFCC ? 4 : 3) <= 16384 &&
+                (cfg->output == AA_OUT_LOGMEL || fuse_dct)) {
+                std::vector<double> w;
+                std::vector<float> mt;
+                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
+                if (build_mel_mfma(w, nb, cfg->n_mels, &mt, &p->mel_mfma_sched)) {
+                    AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
+                    AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
+                    p->mel_mfma = true;
+                }
+            }
+            if (((ok && p->mel_resident && aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384) || p->mel_mfma) &&
+                fuse_dct) {
                 std::vector<float> dl((size_t)aa::kMfccTableDwords, 0.0f);
                 for (int tile = 0; tile < aa::kMfccTiles; ++tile)
                     for (int S = 0; S < 4; ++S)
@@ -1048,7 +1234,8 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                             }
                 AA_HIP(hipMalloc(&p->d_dct_lane, dl.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_dct_lane, dl.data(), dl.size() * sizeof(float), hipMemcpyHostToDevice));
-                p->mfcc_fused = true;
+                p->mfcc_fused = ok && p->mel_resident && aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384;
+                p->mfcc_mfma = p->mel_mfma;
             }
         }
         return AA_OK;
@@ -1073,7 +1260,7 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
             (void)hipStreamDestroy(st);
     if (p->pipe_event)
         (void)hipEventDestroy(p->pipe_event);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_w1024x2_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_dct_lane,
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_w1024x2_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_mel_mfma, p->d_dct_lane,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
@@ -1145,7 +1332,8 @@ int aa_stft_execute_channels_device(aa_stft_plan *p, const float *samples_dev, i
     // slab paths of MFCC / mel) and the channels keep the 16-byte alignment of the first one
     const bool mel = p->cfg.output == AA_OUT_LOGMEL || p->cfg.output == AA_OUT_MFCC;
     const bool single_kernel = (p->wave1024 || p->wave2048) &&
-                               (!mel || (p->fused_mel && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_fused)));
+                               (!mel || (p->fused_mel && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_fused)) ||
+                                (p->mel_mfma && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_mfma)));
     const bool aligned = ((channel_stride | out_channel_stride) & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(samples_dev) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
@@ -1216,6 +1404,21 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
     // mel / MFCC, fused: the wave kernel reduces each power row to n_mels log-mel values in LDS
     // (triangular gather); MFCC adds the dense DCT-II as an f32 MFMA GEMM over log-mel slabs.
     const float *first_sample = samples_dev + frame_begin * (int64_t)p->cfg.hop;
+    if (p->mel_mfma && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
+        // r4: the contraction on v_mfma_f32_4x4x1_16b_f32 inside the 1024 kernel (rows leave as dwordx4 pieces: 16-byte-aligned out)
+        if (p->cfg.output == AA_OUT_LOGMEL && (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0 &&
+            (!chn || (chn->out_stride & 3) == 0)) {
+            AA_HIP(aa::launch_wave1024(aa::kLogMelM, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf, p->cfg.hop,
+                                       p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, nullptr, 0, chn));
+            return AA_OK;
+        }
+        if (p->cfg.output == AA_OUT_MFCC && p->mfcc_mfma) {
+            AA_HIP(aa::launch_wave1024(aa::kMfccM, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf, p->cfg.hop,
+                                       p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, p->d_dct_lane,
+                                       p->cfg.n_mfcc, chn));
+            return AA_OK;
+        }
+    }
     if (p->fused_mel && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
         auto mel_stage = [&](int64_t fb, int64_t n, float *dst) -> int {
             if (p->wave2048)

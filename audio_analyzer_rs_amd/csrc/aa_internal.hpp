@@ -33,7 +33,10 @@ struct DeviceGuard {
 // the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
 // kMfccR: kLogMelR + the DCT-II fused behind it (1024 kernel only): the log-mel rows of 16 frames stay
 // in LDS and go through v_mfma_f32_16x16x4_f32 (see stft_wave1024_kernel).
-enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5, kMfccR = 6 };
+// kLogMelM / kMfccM (r4, 1024 kernel, 8 frames per chunk): the mel contraction band-blocked on
+// v_mfma_f32_4x4x1_16b_f32 (see "band-blocked mel contraction" below); kMfccM adds the fused DCT-II.
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5, kMfccR = 6,
+                     kLogMelM = 7, kMfccM = 8 };
 
 // ---- fused mel reduction (wave kernels, kLogMel) ------------------------------------
 // The filterbank is triangular: 98 % zeros, every bin feeds at most two filters, so the fused
@@ -88,6 +91,32 @@ constexpr int kMelResidentTableDwords = kMelResidentSteps1024 * 5 * 64;
 constexpr int kMelStreamMaxSteps = 16;
 constexpr int kMelStreamTableDwords = kMelStreamMaxSteps * 64 * 4 + 64 * 8;
 
+// ---- band-blocked mel contraction on the matrix cores (kLogMelM / kMfccM, r4) -------------------
+// After a workgroup barrier the power rows of all 8 frames of a chunk are visible in the four waves'
+// scratch areas, and every wave contracts a QUARTER OF THE FILTERBANK with all 8 frames instead of
+// the whole filterbank with its own 2: v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 x 1
+// products (block = lane / 4; A: i = lane % 4, B: j = lane % 4, D[register i][j]; measured 8.9 cycles
+// with four accumulators, 9.8 with two: tools/ubench_mfma4x4.hip), here block = a quad of 4
+// consecutive mels (i) x 4 frames (j) x one bin (k), each block walking ITS OWN bin range - the band
+// structure of the triangular filterbank (2 of the 4 mels of a quad are non-zero at any bin, against
+// 2 of 128 for a dense GEMM).  A step is 4 bins: one ds_read_b128 of the power row (B operand, 4
+// MFMAs' worth) and one resident float4 of weights (A operand) per lane; frames j and 4 + j share the
+// A operand (two accumulator sets).  A quad of more than kMelMfmaSteps pieces is cut into K-slices on
+// consecutive blocks of the wave; every block leaves its 4 x 8 partial sums in LDS (the chunk's sample
+// buffer is dead by then) and the wave's lanes, re-labelled (quad slot, frame), add the slices of
+// their quad, take the logs and write the 16-byte piece of the row: all 64 lanes busy for 8 quads.
+// Per-wave table: [kMelMfmaSteps][64][4] weights, then [2][64] dwords: the byte offset of the lane's
+// first piece in a power row, and the emission word of the lane as (quad slot = lane / 8, frame =
+// lane % 8): bits 0-4 slices of the quad (0: idle lane), 5-8 its first block, 9-13 the quad,
+// 24-28 the wave's largest slice count (the same in every lane).
+constexpr int kMelMfmaSteps = 4;
+constexpr int kMelMfmaRowB = 528;                   // float offset of the wave's second power row in its scratch
+constexpr int kMelMfmaScratchDwords = 1072;         // scratch stride of these kinds: 268 float4 = 12 mod 16 -> the four
+                                                    // frames a block reads sit in four different bank quarters
+constexpr int kMelMfmaWaveDwords = kMelMfmaSteps * 64 * 4 + 2 * 64;
+constexpr int kMelMfmaTableDwords = 4 * kMelMfmaWaveDwords;
+constexpr int kMelMfmaPartDwords = 4 * 2 * 64 * 4;  // partial sums of a workgroup: [wave][frame set][lane][4]
+
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see
 // build_wave1024_table in aa_abi.cpp for the row meaning).
@@ -96,10 +125,14 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
 // LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
 // of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
-// mel: 0 none, 1 fused mel reduction (kLogMel / kLogMelR), 2 fused MFCC (kMfccR)
+// mel: 0 none, 1 fused mel reduction (kLogMel / kLogMelR), 2 fused MFCC (kMfccR), 3 kLogMelM, 4 kMfccM
 inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int mel = 0)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
+    // (the partial sums of the mel contraction live in the chunk's dead sample buffer when it is large enough)
+    if (mel >= 3)
+        return 2 * span + 4 * kMelMfmaScratchDwords + (mel == 4 ? kMfccLdsDwords : 0) + 4 +
+               (span < kMelMfmaPartDwords ? kMelMfmaPartDwords : 0);       // (+ 4: the zero slot of the slice sums)
     return 2 * span + 4 * kWave1024ScratchDwords + (mel == 2 ? kMfccLdsDwords : mel ? kMelLdsDwords : 0);
 }
 inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int mel = 0)
@@ -122,7 +155,7 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
                            const Channels *channels = nullptr);
 
 // kMfccR of launch_wave1024, defined in aa_kernels_mfcc.hip (arguments already validated by launch_wave1024)
-hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+hipError_t launch_wave1024_mfcc(bool mfma_mel, const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
                                 int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
                                 const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch);
 

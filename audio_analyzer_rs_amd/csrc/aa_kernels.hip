@@ -127,7 +127,7 @@ __device__ __forceinline__ float bin_from_power(float p, float log_floor)
 {
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR || OUT == kLogMelM || OUT == kMfccM)
         return p;
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
 }
@@ -138,7 +138,7 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
     float p = re * re + im * im;
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR || OUT == kLogMelM || OUT == kMfccM)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
@@ -774,6 +774,25 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- kLogMelM / kMfccM: the mel contraction band-blocked on v_mfma_f32_4x4x1_16b_f32 (aa_internal.hpp) ----
+// Per-lane residents of a wave: the float4 of weights of its (block, mel i) per step, the byte offset of the
+// block's first 4-bin piece in a power row and the emission word (aa_internal.hpp).
+struct MelMfma {
+    v4f w[kMelMfmaSteps];
+    unsigned off;
+    unsigned emit;
+};
+__device__ __forceinline__ void mel_mfma_load(MelMfma &mm, const float *tab_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const v4f *w4 = reinterpret_cast<const v4f *>(tab_wave);
+#pragma unroll
+    for (int s = 0; s < kMelMfmaSteps; ++s)
+        mm.w[s] = w4[s * 64 + lane];
+    const unsigned *u = reinterpret_cast<const unsigned *>(tab_wave + kMelMfmaSteps * 64 * 4);
+    mm.off = u[lane];
+    mm.emit = u[64 + lane];
+}
 // The SIMD's instruction arbiter serves waves by priority, then age.  With equal priorities the
 // workgroups that share a CU do not progress together: they finish one after the other in dispatch
 // order (measured: 38 / 50 / 62 / 73 us for the four residents of every CU,
@@ -1652,6 +1671,397 @@ void stft_wave1024_kernel(
     }
     flush_dct();
     AA_CLK_END
+}
+
+// ------------------------------- n_fft = 1024, log-mel / MFCC rows (kLogMelM / kMfccM, r4) --
+// stft_wave1024_mel_kernel: the FFT of stft_wave1024_kernel (same passes, same scratch images, 8 frames per
+// chunk, wave w owns frames w and w + 4 interleaved phase by phase) with the mel contraction band-blocked on
+// v_mfma_f32_4x4x1_16b_f32 (MelMfma above, aa_internal.hpp).  The contraction needs the eight power rows of the
+// chunk, i.e. a workgroup barrier (B1) behind the epilogues, and the next chunk's exchanges overwrite the rows,
+// i.e. a second one (T, also the barrier that says "chunk c + 1 has landed"):
+//     loop over chunks c:   frame reads, window, pass A, exchange 1, passes B / C, split, power rows of chunk c
+//                           wait for this wave's LDS-DMA pieces of chunk c + 1;  barrier B1
+//                           row reads | 32 MFMAs | partial sums through LDS | logs | row pieces of chunk c (kMfccM:
+//                           log-mel rows into the 16-frame block)
+//                           barrier T;  LDS-DMA of chunk c + 2 into the buffer chunk c's samples and partial sums used
+//                           kMfccM, every second chunk: DCT-II of the block on v_mfma_f32_16x16x4_f32 (behind T: no
+//                           barrier of its own)
+// Vector-memory order per wave: .. store(c - 1) | DMA(c + 1) | .. | store(c) | DMA(c + 2): the wait in front of B1
+// is a plain vmcnt(0) - everything it covers was issued most of a chunk ago (timing-only ablation without the
+// DMA: same launch time).  Measured and rejected (tools/experiments/r04_mel_kernel_pipelined.diff): the front half of
+// chunk c + 1 (frame reads, window, pass A - registers only) inside the phase between B1 and T, to fill its chain of
+// latencies: 85.4 us against 77.2 (the exchanges' LDS round trip is then exposed at the chunk top, and the LDS-DMA has
+// half a chunk instead of a whole one to land: 82.7 us without any DMA).
+// LDS: [2][span] samples | 4 x kMelMfmaScratchDwords | kMfccM: the log-mel block [16][kMfccRowStride] | a zero
+// float4 | the partial sums when a sample buffer is too small for them (hops below 147).
+#ifndef AA_MELP_PRIO
+#define AA_MELP_PRIO 2103  // r4: 74.7 us against 78.8 with the rotation (log-mel), 84.8 against 91.0 (MFCC); 3210 75.5, 3103 / 3203 / 2102 within 0.5 % of 2103, 2113 / 2003 / 1003 lose 5 %
+#endif
+// wave priority of stft_wave1024_mel_kernel at its four points (chunk top, behind the exchanges, power rows, mel phase):
+// 1 = the four-level rotation of stft_wave1024_kernel; abcd (decimal digits) = level by phase, the same in every workgroup
+__device__ __forceinline__ void mel_prio(int point, int prio_step)
+{
+    if (AA_MELP_PRIO == 0)
+        return;
+    if (AA_MELP_PRIO == 1) {
+        rotate_wave_priority(prio_step + point);
+        return;
+    }
+    const int lvl = point == 0 ? (AA_MELP_PRIO / 1000) % 10 : point == 1 ? (AA_MELP_PRIO / 100) % 10
+                  : point == 2 ? (AA_MELP_PRIO / 10) % 10 : AA_MELP_PRIO % 10;
+    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+    if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+}
+#ifndef AA_MELP_ABL
+#define AA_MELP_ABL 0      // timing-only ablations (wrong rows): 1 no LDS-DMA behind the first two chunks
+#endif
+template <int OUT>
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(OUT == kMfccM ? 3 : 1)))
+void stft_wave1024_mel_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int hop, int64_t n_chunks,
+    float log_floor, const float *__restrict__ mel_tab, int n_mels, const float *__restrict__ dct_tab,
+    int n_mfcc, int n_streams, int64_t stream_in_stride, int64_t stream_out_stride)
+{
+    static_assert(OUT == kLogMelM || OUT == kMfccM, "mel kinds only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool MFCC = OUT == kMfccM;
+    constexpr int kScr = kMelMfmaScratchDwords, FPW = 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int vgrid, vblock;
+    {
+        int64_t in_off, out_off;
+        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
+        x += in_off;
+        out += out_off;
+    }
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1, vgrid, vblock);
+    if (c0 >= c1)
+        return;                                              // (workgroup-uniform)
+    const int max_span = (FPW - 1) * hop + 1024;
+    float *scr0 = smem + 2 * max_span;
+    v2f *scr = reinterpret_cast<v2f *>(scr0 + wave * kScr);
+    float *lm = scr0 + 4 * kScr;                             // kMfccM: log-mel rows of two chunks
+    float *tail = lm + (MFCC ? kMfccLdsDwords : 0);          // [zero float4][partial sums, if not in a sample buffer]
+    const int COLS = MFCC ? n_mfcc : n_mels;
+    const int64_t first_frame = (int64_t)c0 * FPW;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
+    float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
+    int frames_left = (int)(n_frames - first_frame);                            // from chunk c on
+    const int src_stride = FPW * hop, out_stride = FPW * COLS;
+
+    // LDS-DMA of `nfc` frames' samples starting at src into buffer `which` (wave w moves the 1 KiB pieces w, w + 4, ..)
+    auto stage = [&](const float *src, int nfc, int which) {
+        const int span4 = ((nfc - 1) * hop + 1024) >> 2;
+        float *dst = smem + which * max_span;
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
+            const int q = qb + lane;
+            if (q < span4)
+                lds_dma_16(src + 4 * q, dst + 4 * qb);
+        }
+    };
+    stage(src_chunk, frames_left < FPW ? frames_left : FPW, 0);
+
+    // per-lane constants as packed pairs (rows of the plan's table as in stft_wave1024_kernel)
+    v2f win[8], twA[8], twB[8], tws[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = v2f{tab[(16 + 2 * (k - 1)) * 64 + lane], tab[(17 + 2 * (k - 1)) * 64 + lane]};
+        twB[k] = v2f{tab[(30 + 2 * (k - 1)) * 64 + lane], tab[(31 + 2 * (k - 1)) * 64 + lane]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        tws[j] = v2f{tab[(44 + 2 * j) * 64 + lane], tab[(45 + 2 * j) * 64 + lane]};
+    MelMfma mmf;
+    mel_mfma_load(mmf, mel_tab + wave * kMelMfmaWaveDwords);
+    if (MFCC)
+        for (int i = tid; i < kMfccLdsDwords; i += kWave1024Threads)
+            lm[i] = 0.0f;                    // columns past n_mels are read by the DCT (zero weights): keep them finite
+    if (tid < 4)
+        tail[tid] = 0.0f;                    // the zero slot of the slice sums
+    const unsigned smem_addr = lds_addr(smem);
+    v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
+    const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
+
+    // ---- pieces of the transform (see stft_wave1024_kernel for the maps) ----
+    auto read_frames = [&](int buf, v2f (&a)[8], v2f (&b)[8]) {             // frames wave and wave + 4 of the buffer
+        const unsigned fa = smem_addr + 4u * (unsigned)(buf * max_span + 2 * lane + wave * hop);
+        const unsigned fb = fa + 16u * (unsigned)hop;
+        a[0] = lds_read_b64<0>(fa); a[1] = lds_read_b64<512>(fa); a[2] = lds_read_b64<1024>(fa); a[3] = lds_read_b64<1536>(fa);
+        a[4] = lds_read_b64<2048>(fa); a[5] = lds_read_b64<2560>(fa); a[6] = lds_read_b64<3072>(fa); a[7] = lds_read_b64<3584>(fa);
+        b[0] = lds_read_b64<0>(fb); b[1] = lds_read_b64<512>(fb); b[2] = lds_read_b64<1024>(fb); b[3] = lds_read_b64<1536>(fb);
+        b[4] = lds_read_b64<2048>(fb); b[5] = lds_read_b64<2560>(fb); b[6] = lds_read_b64<3072>(fb); b[7] = lds_read_b64<3584>(fb);
+    };
+    auto pass_a = [&](v2f (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = v[j] * win[j];
+        pk_dft8(v);
+        pk_twiddle7(v, twA);
+    };
+    auto exchange1 = [&](v2f (&v)[8]) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            e1_wr[8 * kk] = v[kk];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v4f qv = e1_rd[i];
+            v[2 * i] = v2f{qv.x, qv.y};
+            v[2 * i + 1] = v2f{qv.z, qv.w};
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto pass_bc = [&](v2f (&v)[8]) {
+        pk_dft8(v);
+        pk_twiddle7(v, twB);
+        hazard_fence(v);   // packed asm -> DPP / permlane read
+        exchange_high(v);
+        pk_dft8(v);
+    };
+    auto strip = [&](v2f (&v)[8], v2f (&prt)[4]) {   // partner half through the LDS strip
+#pragma unroll
+        for (int j = 4; j < 8; ++j)
+            scr[lane + 64 * (j - 4)] = v[j];
+        if (lane == 0)
+            scr[256] = v[0];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            prt[j] = scr[256 - (lane + 64 * j)];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto power_row = [&](v2f (&v)[8], v2f (&prt)[4], int slot) {           // |X[k]|^2, k = 0..512 -> the wave's row `slot`
+        v2f se[4], so[4], st[4], re[4], im[4], pw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            se[j] = pk_add_conj(v[j], prt[j]);
+            so[j] = pk_sub_conj(v[j], prt[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st[j] = pk_cmul_lo(so[j], tws[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st[j] = pk_cmul_hi(so[j], tws[j], st[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            re[j] = pk_sum_diff_re(se[j], st[j]);
+            im[j] = pk_sum_diff_im(se[j], st[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pw[j] = re[j] * re[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pw[j] = im[j] * im[j] + pw[j];
+        const float m256 = bin_value<kPower>(2.0f * v[4].x, 2.0f * v[4].y, log_floor);
+        float *lrow = reinterpret_cast<float *>(scr) + slot * kMelMfmaRowB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lrow[lane + 64 * j] = pw[j].x;
+            lrow[512 - lane - 64 * j] = pw[j].y;
+        }
+        if (lane == 0)
+            lrow[256] = m256;
+        // the row's last float4 piece is read whole (bin 512 + three floats with zero weights): keep those finite
+        // whatever another frame left in the scratch
+        if (lane < 3)
+            lrow[513 + lane] = 0.0f;
+    };
+
+    // kMfccM: accumulators of the last DCT block, stored from the top of the next chunk (the MFMAs drain meanwhile)
+    v4f pend0 = {0.0f, 0.0f, 0.0f, 0.0f}, pend1 = pend0;
+    float *pend_row = nullptr;
+    int pend_coef0 = 0;
+    bool pending = false;
+    auto flush_dct = [&]() {
+        if (MFCC && pending) {
+            const v4f d = pend0 + pend1;
+            if (pend_row) {
+                if (pend_coef0 + 0 < n_mfcc) pend_row[0] = d.x;
+                if (pend_coef0 + 2 < n_mfcc) pend_row[2] = d.y;
+                if (pend_coef0 + 4 < n_mfcc) pend_row[4] = d.z;
+                if (pend_coef0 + 6 < n_mfcc) pend_row[6] = d.w;
+            }
+            pending = false;
+        }
+    };
+
+    // ---- prologue: chunk c0 has landed ----
+    wait_vmcnt_le<0>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    if (c0 + 1 < c1) {
+        const int nleft = frames_left - FPW;
+        stage(src_chunk + src_stride, nleft < FPW ? nleft : FPW, 1);
+    }
+
+    int it = 0;
+    for (int c = c0; c < c1; ++c, ++it) {
+        const int cur = it & 1;
+        const int nf = frames_left < FPW ? frames_left : FPW;
+        const bool has_next = c + 1 < c1;
+        const int prio_step = (int)(blockIdx.x >> 8) + 4 * it;
+        mel_prio(0, prio_step);
+        flush_dct();
+        // ---- the transform of the wave's two frames, phase by phase, and their power rows ----
+        {
+            v2f va[8], vbv[8], pa[4], pb[4];
+            read_frames(cur, va, vbv);      // (a wave without a frame transforms stale samples: nothing of it is stored)
+            lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+            lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
+            pass_a(va);
+            exchange1(va);
+            pass_a(vbv);
+            exchange1(vbv);
+            mel_prio(1, prio_step);
+            pass_bc(va);
+            strip(va, pa);
+            pass_bc(vbv);
+            strip(vbv, pb);
+            mel_prio(2, prio_step);
+            power_row(va, pa, 0);
+            power_row(vbv, pb, 1);
+        }
+        wait_vmcnt_le<0>();                  // this wave's pieces of chunk c + 1 (and whatever was stored before them)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();        // B1: the eight power rows are written, chunk c + 1 has landed
+        mel_prio(3, prio_step);
+
+        // ---- the mel contraction of chunk c with the front half of chunk c + 1 inside it ----
+        int ln = lane;
+        asm volatile("" : "+v"(ln));         // (opaque: per-lane addresses are not hoisted out of the chunk loop)
+        const v4f *q = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(scr0 + (ln & 3) * kScr) + mmf.off);
+        v4f b0[kMelMfmaSteps], b1[kMelMfmaSteps];
+#pragma unroll
+        for (int s = 0; s < kMelMfmaSteps; ++s) {
+            b0[s] = q[s];
+            b1[s] = q[s + kMelMfmaRowB / 4];
+        }
+        v4f d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = d0;
+#pragma unroll
+        for (int s = 0; s < kMelMfmaSteps; ++s) {            // (steps past the plan's carry zero weights)
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].x, b0[s].x, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].x, b1[s].x, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].y, b0[s].y, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].y, b1[s].y, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].z, b0[s].z, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].z, b1[s].z, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].w, b0[s].w, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(mmf.w[s].w, b1[s].w, d1, 0, 0, 0);
+        }
+        // partial sums of (block, frame) -> LDS: this chunk's sample buffer is dead (every wave read its frames a chunk
+        // ago; the next LDS-DMA into it is issued behind barrier T)
+        float *part = (max_span >= kMelMfmaPartDwords ? smem + cur * max_span : tail + 4) + wave * (2 * 64 * 4);
+        v4f *p4 = reinterpret_cast<v4f *>(part);
+        p4[ln] = d0;
+        p4[64 + ln] = d1;
+        __builtin_amdgcn_wave_barrier();
+        // lanes re-labelled (quad slot, frame f = lane % 8): the slices of the quad (consecutive blocks), four per round
+        unsigned em = mmf.emit;
+        asm volatile("" : "+v"(em));
+        const int ns = (int)(em & 31u), blk0 = (int)((em >> 5) & 15u);
+        const int hmax = __builtin_amdgcn_readfirstlane((int)(em >> 24) & 31);
+        const v4f *src = p4 + ((ln & 4) << 4) + 4 * blk0 + (ln & 3);      // set f / 4, lane 4 blk0 + f % 4
+        const v4f *z4 = reinterpret_cast<const v4f *>(tail);
+        v4f m4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int h0 = 0; h0 < hmax; h0 += 4) {
+            const v4f t0 = *(h0 + 0 < ns ? src + 4 * (h0 + 0) : z4);
+            const v4f t1 = *(h0 + 1 < ns ? src + 4 * (h0 + 1) : z4);
+            const v4f t2 = *(h0 + 2 < ns ? src + 4 * (h0 + 2) : z4);
+            const v4f t3 = *(h0 + 3 < ns ? src + 4 * (h0 + 3) : z4);
+            m4 += (t0 + t1) + (t2 + t3);
+        }
+        if (ns != 0) {                                       // (quad slot, frame): the quad's four mels of one frame
+            const int q4 = (int)((em >> 9) & 31u) * 4, f = ln & 7;
+            v4f l4;
+            l4.x = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m4.x, log_floor));
+            l4.y = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m4.y, log_floor));
+            l4.z = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m4.z, log_floor));
+            l4.w = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m4.w, log_floor));
+            if (!MFCC) {
+                // rows of n_mels floats (a multiple of 4, 16-byte-aligned buffer): one dwordx4 per (quad, frame)
+                if (f < nf)
+                    *reinterpret_cast<v4f *>(out_chunk + __mul24(f, COLS) + q4) = l4;
+            } else {
+                // row 8 (chunk parity) + frame of the log-mel block (rows 0..7 were read by the DCT a chunk pair ago)
+                *reinterpret_cast<v4f *>(lm + (8 * (it & 1) + f) * kMfccRowStride + q4) = l4;
+            }
+        }
+        const bool dct_now = MFCC && ((it & 1) || !has_next);
+        // kMfccM: the A operand of the DCT (plan table, L2 resident) is fetched in front of the barrier
+        v4f a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+        if (dct_now) {
+            const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + ln;
+            a0 = at[0]; a1 = at[64]; a2 = at[128]; a3 = at[192];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();        // T: every wave is done with the rows, the partial sums and the sample buffer
+        if (c + 2 < c1 && !(AA_MELP_ABL & 1)) {
+            const int nleft = frames_left - 2 * FPW;
+            stage(src_chunk + 2 * src_stride, nleft < FPW ? nleft : FPW, cur);
+        }
+        if (dct_now) {
+            // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores (see stft_wave1024_kernel): wave w owns
+            // the 16 coefficients c = 2 (16 (w & 1) + i) + (w >> 1); the fold about the middle of the mel axis happens in the
+            // B operand: u[m] = L[m] + L[M-1-m] for the even coefficients' tiles, v[m] = L[m] - L[M-1-m] for the odd ones
+            // (M % 4 == 0: the mirrored float4 is aligned; m >= M / 2 carries zero weights and reads finite values)
+            const float *rowp = lm + (ln & 15) * kMfccRowStride;
+            const int mq = 4 * (ln >> 4);
+            v4f bb[4];
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const int ma = 16 * S + mq;
+                int mb = n_mels - 4 - ma;
+                mb = mb < 0 ? ma : mb;
+                const v4f a = *reinterpret_cast<const v4f *>(rowp + ma);
+                const v4f r = *reinterpret_cast<const v4f *>(rowp + mb);
+                bb[S] = (wave >> 1) ? v4f{a.x - r.w, a.y - r.z, a.z - r.y, a.w - r.x}
+                                    : v4f{a.x + r.w, a.y + r.z, a.z + r.y, a.w + r.x};
+            }
+            v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb[0].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb[1].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb[0].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb[1].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bb[0].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bb[1].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bb[0].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bb[1].w, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bb[2].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, bb[3].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bb[2].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, bb[3].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, bb[2].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, bb[3].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bb[2].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, bb[3].w, acc1, 0, 0, 0);
+            // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
+            const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
+            const int have = (it & 1) ? 8 + nf : nf;               // valid rows (a lone last chunk: rows 0..7)
+            // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's
+            float *orow = ((it & 1) ? (j < 8 ? out_chunk - out_stride + j * COLS : out_chunk + (j - 8) * COLS)
+                                    : out_chunk + j * COLS) + coef0;
+            pend0 = acc0;
+            pend1 = acc1;
+            pend_row = j < have ? orow : nullptr;
+            pend_coef0 = coef0;
+            pending = true;
+        }
+        src_chunk += src_stride;
+        out_chunk += out_stride;
+        frames_left -= FPW;
+    }
+    flush_dct();
 }
 
 // ------------------------------ two frames per wave, n_fft = 1024 at hop 256 (BASELINE geometry) --
@@ -3628,14 +4038,39 @@ static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, co
     return hipGetLastError();
 }
 
+// kLogMelM / kMfccM: stft_wave1024_mel_kernel (8 frames per chunk; arguments validated by launch_wave1024)
+template <int K>
+static hipError_t launch_wave1024_mel_kind(const float *x, float *out, const float *table, int64_t frame_begin,
+                                           int64_t n_frames, int hop, float log_floor, hipStream_t stream,
+                                           const float *mel_tab, const MelSched &sch, const float *dct_tab, int n_mfcc,
+                                           const Channels &ch)
+{
+    const int64_t chunks = (n_frames + 7) / 8;
+    const size_t lds = wave1024_lds_bytes(8, hop, K == kMfccM ? 4 : 3);
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    static thread_local size_t cached_lds = 0;
+    if (cached_grid == 0 || cached_lds != lds) {
+        cached_grid = persistent_grid(stft_wave1024_mel_kernel<K>, lds);
+        cached_lds = lds;
+    }
+    const int64_t want = experiment_knob("AA_GRID_SET", cached_grid, 1, 1 << 16);
+    const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
+    hipLaunchKernelGGL((stft_wave1024_mel_kernel<K>), grid, block, lds, stream, x, out, table, frame_begin, n_frames, hop,
+                       chunks, log_floor, mel_tab, sch.n_mels, dct_tab, n_mfcc, ch.n, ch.in_stride, ch.out_stride);
+    return hipGetLastError();
+}
+
 #ifdef AA_TU_MFCC
 // aa_kernels_mfcc.hip: this file once more, for the fused MFCC instantiation of stft_wave1024_kernel alone, compiled with
 // -mllvm -amdgpu-sched-strategy=max-ilp (r3: -2.5 % for that kernel, 94.9 -> 92.6 us; as a flag of the whole library it makes nine
 // fallback instantiations of the 2048 kernel spill and costs the 256 kernel a wave per SIMD, csrc/Makefile).
-hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+hipError_t launch_wave1024_mfcc(bool mfma_mel, const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
                                 int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
                                 const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch)
 {
+    if (mfma_mel)
+        return launch_wave1024_mel_kind<kMfccM>(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch,
+                                                dct_tab, n_mfcc, ch);
     return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream,
                                         mel_par, sch, dct_tab, n_mfcc, ch);
 }
@@ -3656,7 +4091,14 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     if ((out_kind == kLogMelR || out_kind == kMfccR) &&
         (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
         return hipErrorInvalidValue;
-    if (out_kind == kMfccR && (!dct_tab || n_mfcc < 1 || n_mfcc > 16 * kMfccTiles || sch.n_mels > kMelMaxMels))
+    if ((out_kind == kLogMelM || out_kind == kMfccM) &&
+        (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelMfmaSteps || frames_per_wg != 8 || sch.n_mels < 16 ||
+         sch.n_mels > kMelMaxMels || (sch.n_mels & 3)))
+        return hipErrorInvalidValue;
+    if (out_kind == kLogMelM && (reinterpret_cast<uintptr_t>(out) & 15u))   // dwordx4 row pieces
+        return hipErrorInvalidValue;
+    if ((out_kind == kMfccR || out_kind == kMfccM) &&
+        (!dct_tab || n_mfcc < 1 || n_mfcc > 16 * kMfccTiles || sch.n_mels > kMelMaxMels))
         return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
@@ -3673,9 +4115,12 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
         return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kLogMelR:
         return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+    case kLogMelM:
+        return launch_wave1024_mel_kind<kLogMelM>(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch, nullptr, 0, ch);
     case kMfccR:   // built in a translation unit of its own (aa_kernels_mfcc.hip: another scheduler strategy)
-        return launch_wave1024_mfcc(x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch,
-                                    dct_tab, n_mfcc, ch);
+    case kMfccM:
+        return launch_wave1024_mfcc(out_kind == kMfccM, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream,
+                                    mel_par, sch, dct_tab, n_mfcc, ch);
     default:
         return hipErrorInvalidValue;
     }
