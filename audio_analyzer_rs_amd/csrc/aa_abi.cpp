@@ -430,13 +430,17 @@ bool build_mel_streamed(const std::vector<double> &w, int nb, int n_mels, std::v
 // and the smallest S that packs wins (fewer steps = fewer MFMAs and fewer resident registers).  The table is
 // verified against the dense filterbank before it is accepted: the kernel's dataflow run on the table must
 // reproduce every f32 weight, each exactly once.
-bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab, aa::MelSched *sch)
+// n_fft 1024: S_MAX = kMelMfmaSteps, 8 frames per emission slot (8 slots per wave), rows of kMelMfmaRowB floats;
+// n_fft 2048: S_MAX = kMelMfmaSteps2048, steps_gated (the kernel multiplies n_steps steps only), 8 lanes per slot too (4 frames
+// x the two halves of the quad).
+bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, int S_MAX, int frames_per_slot, int row_floats,
+                    bool steps_gated, std::vector<float> *tab, aa::MelSched *sch)
 {
-    constexpr int S_MAX = aa::kMelMfmaSteps;
     if (n_mels < 16 || n_mels > aa::kMelMaxMels || (n_mels & 3) || 4 * nb > 65535)
         return false;
     const int nq = n_mels / 4, pieces_max = (nb + 3) / 4;   // pieces 0 .. pieces_max - 1
-    if (4 * pieces_max > aa::kMelMfmaRowB || pieces_max < S_MAX)
+    const int slots = 64 / frames_per_slot, wave_dwords = S_MAX * 64 * 4 + 2 * 64;
+    if (4 * pieces_max > row_floats || pieces_max < S_MAX)
         return false;
     std::vector<int> c_lo(nq, 0), c_n(nq, 0);
     for (int q = 0; q < nq; ++q) {
@@ -474,7 +478,7 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
         for (const auto &it : items) {
             int best = -1;
             for (int wv = 0; wv < 4; ++wv)
-                if (free_blocks[wv] >= it.first && quads[wv] < 8 && (best < 0 || free_blocks[wv] > free_blocks[best]))
+                if (free_blocks[wv] >= it.first && quads[wv] < slots && (best < 0 || free_blocks[wv] > free_blocks[best]))
                     best = wv;
             if (best < 0) {
                 ok = false;
@@ -496,10 +500,11 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
     *sch = aa::MelSched();
     sch->n_mels = n_mels;
     sch->n_steps = S;
-    tab->assign((size_t)aa::kMelMfmaTableDwords, 0.0f);
-    auto wave_tab = [&](int wv) { return tab->data() + (size_t)wv * aa::kMelMfmaWaveDwords; };
+    tab->assign((size_t)4 * wave_dwords, 0.0f);
+    auto wave_tab = [&](int wv) { return tab->data() + (size_t)wv * wave_dwords; };
     auto words = [&](int wv) { return reinterpret_cast<uint32_t *>(wave_tab(wv) + (size_t)S_MAX * 64 * 4); };
     int hmax[4] = {0, 0, 0, 0};
+    int live_steps = S;                                      // a block pushed back from the row's end multiplies later steps
     for (int q = 0; q < nq; ++q)
         hmax[place[q].wave] = std::max(hmax[place[q].wave], place[q].slices);
     for (int wv = 0; wv < 4; ++wv)
@@ -509,18 +514,20 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
         const Place &pl = place[q];
         float *T = wave_tab(pl.wave);
         uint32_t *u = words(pl.wave);
-        for (int f = 0; f < 8; ++f)
-            u[64 + 8 * pl.slot + f] |= (uint32_t)pl.slices | ((uint32_t)pl.blk0 << 5) | ((uint32_t)q << 9);
+        for (int f = 0; f < frames_per_slot; ++f)
+            u[64 + frames_per_slot * pl.slot + f] |= (uint32_t)pl.slices | ((uint32_t)pl.blk0 << 5) | ((uint32_t)q << 9);
         const int per = std::max(1, (c_n[q] + pl.slices - 1) / pl.slices);     // pieces per slice (<= S)
         for (int h = 0; h < pl.slices; ++h) {
             const int blk = pl.blk0 + h;
             const int p0 = c_lo[q] + h * per, p1 = std::min(c_lo[q] + c_n[q], p0 + per);
-            // the block reads (and multiplies: unused steps carry zero weights) kMelMfmaSteps consecutive pieces from
-            // `start`: all of them inside the row
-            const int start = std::max(0, std::min(p0, pieces_max - S_MAX));
+            // the block reads S_MAX consecutive pieces from `start`.  1024 kernel: all of them multiply (unused steps carry
+            // zero weights), so all of them lie inside the row; 2048 kernel (steps_gated): only the first n_steps multiply,
+            // the others may run into the slack behind the row (inside the wave's scratch, never used)
+            const int start = std::max(0, std::min(p0, pieces_max - (steps_gated ? S : S_MAX)));
             for (int i = 0; i < 4; ++i) {
                 const int lane = 4 * blk + i;           // A operand: mel 4 q + i; B operand / partial sums: frame j = i
                 u[lane] = 16u * (uint32_t)start;
+                live_steps = std::max(live_steps, p1 - start);
                 for (int piece = std::max(p0, start); piece < p1; ++piece)
                     for (int t = 0; t < 4; ++t)
                         T[((size_t)(piece - start) * 64 + lane) * 4 + t] =
@@ -528,6 +535,10 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
             }
         }
     }
+    S = live_steps;
+    if (S > S_MAX)
+        return false;
+    sch->n_steps = S;
     // Verification: the kernel's dataflow on the table - per (block, mel i) the weights the MFMAs accumulate over the
     // S live steps, then the slice sums of every (quad slot, frame) lane - against the dense f32 filterbank.
     std::vector<char> emitted(n_mels, 0);
@@ -537,7 +548,8 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
         std::vector<std::vector<float>> x(64, std::vector<float>(4 * (pieces_max + S_MAX), 0.0f));   // per lane = (block, mel i)
         for (int lane = 0; lane < 64; ++lane) {
             const uint32_t off = u[lane];
-            if ((off & 15u) || off / 16 + S_MAX > (uint32_t)pieces_max)
+            if ((off & 15u) || off / 16 + (steps_gated ? S : S_MAX) > (uint32_t)pieces_max ||
+                off / 4 + 4 * S_MAX > (uint32_t)row_floats)
                 return false;
             for (int s = 0; s < S_MAX; ++s)
                 for (int t = 0; t < 4; ++t) {
@@ -547,10 +559,10 @@ bool build_mel_mfma(const std::vector<double> &w, int nb, int n_mels, std::vecto
                     x[lane][off / 4 + 4 * s + t] = v;
                 }
         }
-        for (int slot = 0; slot < 8; ++slot) {
-            const uint32_t em = u[64 + 8 * slot];
-            for (int f = 1; f < 8; ++f)
-                if (u[64 + 8 * slot + f] != em)
+        for (int slot = 0; slot < slots; ++slot) {
+            const uint32_t em = u[64 + frames_per_slot * slot];
+            for (int f = 1; f < frames_per_slot; ++f)
+                if (u[64 + frames_per_slot * slot + f] != em)
                     return false;
             if ((int)(em >> 24) != hmax[wv])
                 return false;
@@ -1209,7 +1221,20 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 std::vector<double> w;
                 std::vector<float> mt;
                 mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
-                if (build_mel_mfma(w, nb, cfg->n_mels, &mt, &p->mel_mfma_sched)) {
+                if (build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps, 8, aa::kMelMfmaRowB, false, &mt, &p->mel_mfma_sched)) {
+                    AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
+                    AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
+                    p->mel_mfma = true;
+                }
+            }
+            // the same on the 2048 kernel at the tuner hop (BASELINE configs[2]: stft_wave2048_mel_kernel)
+            if (p->wave2048 && cfg->hop == 512 && p->frames_per_wg == 4 && cfg->output == AA_OUT_LOGMEL &&
+                !(no_mfma && std::atoi(no_mfma) == 0)) {
+                std::vector<double> w;
+                std::vector<float> mt;
+                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
+                if (build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps2048, 8, aa::kMelMfmaScratchDwords, true, &mt,
+                                   &p->mel_mfma_sched)) {
                     AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
                     AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
                     p->mel_mfma = true;
@@ -1408,8 +1433,12 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
         // r4: the contraction on v_mfma_f32_4x4x1_16b_f32 inside the 1024 kernel (rows leave as dwordx4 pieces: 16-byte-aligned out)
         if (p->cfg.output == AA_OUT_LOGMEL && (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0 &&
             (!chn || (chn->out_stride & 3) == 0)) {
-            AA_HIP(aa::launch_wave1024(aa::kLogMelM, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf, p->cfg.hop,
-                                       p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, nullptr, 0, chn));
+            if (p->wave2048)
+                AA_HIP(aa::launch_wave2048(aa::kLogMelM, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf, p->cfg.hop,
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, chn));
+            else
+                AA_HIP(aa::launch_wave1024(aa::kLogMelM, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf, p->cfg.hop,
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, nullptr, 0, chn));
             return AA_OK;
         }
         if (p->cfg.output == AA_OUT_MFCC && p->mfcc_mfma) {

@@ -116,6 +116,11 @@ constexpr int kMelMfmaScratchDwords = 1072;         // scratch stride of these k
 constexpr int kMelMfmaWaveDwords = kMelMfmaSteps * 64 * 4 + 2 * 64;
 constexpr int kMelMfmaTableDwords = 4 * kMelMfmaWaveDwords;
 constexpr int kMelMfmaPartDwords = 4 * 2 * 64 * 4;  // partial sums of a workgroup: [wave][frame set][lane][4]
+// the 2048 kernel (hop 512, 4 frames per chunk = the 4 columns of a block: one frame set, 8 emission slots of 4 frames x
+// the two halves of a quad per wave; up to 7 steps of resident weights; same per-wave table layout)
+constexpr int kMelMfmaSteps2048 = 7;
+constexpr int kMelMfmaWaveDwords2048 = kMelMfmaSteps2048 * 64 * 4 + 2 * 64;
+constexpr int kMelMfmaTableDwords2048 = 4 * kMelMfmaWaveDwords2048;
 
 // ---- wave-per-frame 1024-point kernel --------------------------------------
 // Per-lane constant table, row-major [kWave1024Rows][64] floats (see
@@ -207,6 +212,13 @@ inline size_t wave2048_ring_lds_bytes(int blocks, int mel_kind)
     return sizeof(float) * (size_t)(blocks * 256 + 4 * kWave1024ScratchDwords +
                                     (mel_kind == 2 ? 4 * kMelStageDwords : mel_kind == 1 ? kMelLdsDwords : 0));
 }
+// stft_wave2048_mel_kernel: the ring, four scratch areas of the mel kinds' stride, a zero float4, [4][64] float4 of partial sums
+inline size_t wave2048_mel_lds_bytes()
+{
+    return sizeof(float) * (size_t)(30 * 256 + 4 * kMelMfmaScratchDwords + 4 + 4 * 64 * 4);
+}
+// kLogMelM (hop 512, 4 frames per chunk, 16-byte-aligned out, n_mels % 4 == 0): mel_par is the kMelMfmaTableDwords2048 table,
+// sched->n_steps the number of steps.
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,

@@ -1697,6 +1697,9 @@ void stft_wave1024_kernel(
 #ifndef AA_MELP_PRIO
 #define AA_MELP_PRIO 2103  // r4: 74.7 us against 78.8 with the rotation (log-mel), 84.8 against 91.0 (MFCC); 3210 75.5, 3103 / 3203 / 2102 within 0.5 % of 2103, 2113 / 2003 / 1003 lose 5 %
 #endif
+#ifndef AA_MELP_PRIO2048
+#define AA_MELP_PRIO2048 2103   // stft_wave2048_mel_kernel: level at the chunk top, behind the exchanges, from the power row on, in the mel phase
+#endif
 // wave priority of stft_wave1024_mel_kernel at its four points (chunk top, behind the exchanges, power rows, mel phase):
 // 1 = the four-level rotation of stft_wave1024_kernel; abcd (decimal digits) = level by phase, the same in every workgroup
 __device__ __forceinline__ void mel_prio(int point, int prio_step)
@@ -1714,9 +1717,6 @@ __device__ __forceinline__ void mel_prio(int point, int prio_step)
     if (lvl == 2) __builtin_amdgcn_s_setprio(2);
     if (lvl == 3) __builtin_amdgcn_s_setprio(3);
 }
-#ifndef AA_MELP_ABL
-#define AA_MELP_ABL 0      // timing-only ablations (wrong rows): 1 no LDS-DMA behind the first two chunks
-#endif
 template <int OUT>
 __global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(OUT == kMfccM ? 3 : 1)))
 void stft_wave1024_mel_kernel(
@@ -1990,6 +1990,7 @@ void stft_wave1024_mel_kernel(
             l4.w = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m4.w, log_floor));
             if (!MFCC) {
                 // rows of n_mels floats (a multiple of 4, 16-byte-aligned buffer): one dwordx4 per (quad, frame)
+                // (a plain store: nontemporal costs this kernel 5 % - 80.3 us against 75.9 - where the 2048 kernel gains 2 %)
                 if (f < nf)
                     *reinterpret_cast<v4f *>(out_chunk + __mul24(f, COLS) + q4) = l4;
             } else {
@@ -2006,10 +2007,8 @@ void stft_wave1024_mel_kernel(
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();        // T: every wave is done with the rows, the partial sums and the sample buffer
-        if (c + 2 < c1 && !(AA_MELP_ABL & 1)) {
-            const int nleft = frames_left - 2 * FPW;
-            stage(src_chunk + 2 * src_stride, nleft < FPW ? nleft : FPW, cur);
-        }
+        // (the LDS-DMA of chunk c + 2 is issued BEHIND the DCT phase: vmcnt retires in order and the compiler's wait for the
+        // DCT's A operand, fetched above, would otherwise cover the fresh DMA)
         if (dct_now) {
             // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores (see stft_wave1024_kernel): wave w owns
             // the 16 coefficients c = 2 (16 (w & 1) + i) + (w >> 1); the fold about the middle of the mel axis happens in the
@@ -2056,6 +2055,10 @@ void stft_wave1024_mel_kernel(
             pend_row = j < have ? orow : nullptr;
             pend_coef0 = coef0;
             pending = true;
+        }
+        if (c + 2 < c1) {
+            const int nleft = frames_left - 2 * FPW;
+            stage(src_chunk + 2 * src_stride, nleft < FPW ? nleft : FPW, cur);
         }
         src_chunk += src_stride;
         out_chunk += out_stride;
@@ -3180,6 +3183,271 @@ void stft_wave2048_kernel(
     }
 }
 
+// ------------------------ n_fft = 2048 at hop 512, log-mel rows (kLogMelM; BASELINE configs[2]) --
+// stft_wave2048_mel_kernel: the transform and the ring staging of stft_wave2048_kernel<.., RING == 2> (one wave per
+// frame, four frames per chunk, LDS-DMA two chunks ahead) with the mel contraction of stft_wave1024_mel_kernel:
+// behind a workgroup barrier (B1) the four power rows of the chunk are visible and every wave contracts a quarter
+// of the filterbank with all four frames on v_mfma_f32_4x4x1_16b_f32 (block = quad of mels x the chunk's 4 frames).
+// Differences to the 1024 kernel: one frame set (4 frames = the 4 columns of a block), 8 emission slots of 4 frames x 2 half quads,
+// up to kMelMfmaSteps2048 steps with the weights RESIDENT (28 registers: the combine and split twiddles make room for
+// them, see below), partial sums in an LDS area of their own (the ring has no dead space).  Vector-memory order per wave:
+// .. twiddle fetches of frame c | DMA(c + 2) | store(c) | fetches of frame c + 1 ..: every fetch is waited for (vmcnt retires in
+// order) before the next DMA round goes out; the chunk-top wait leaves that round and the row store in flight.
+// LDS: 30 blocks of 256 samples | 4 x kMelMfmaScratchDwords | zero float4 | [4][64] float4 of partial sums.
+template <int OUT>
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void stft_wave2048_mel_kernel(
+    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
+    int64_t frame_begin, int64_t n_frames, int64_t n_chunks, float log_floor,
+    const float *__restrict__ mel_tab, int n_mels, int n_steps, int n_streams, int64_t stream_in_stride,
+    int64_t stream_out_stride)
+{
+    static_assert(OUT == kLogMelM, "log-mel rows only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RB = 30, DEPTH = 2, HOP = 512, FPW = 4, kScr = kMelMfmaScratchDwords, SMAX = kMelMfmaSteps2048;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int vgrid, vblock;
+    {
+        int64_t in_off, out_off;
+        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
+        x += in_off;
+        out += out_off;
+    }
+    int c0, c1;
+    chunk_run(n_chunks, c0, c1, vgrid, vblock);
+    if (c0 >= c1)
+        return;                                              // (workgroup-uniform)
+    float *scr0 = smem + RB * 256;
+    v2f *scr = reinterpret_cast<v2f *>(scr0 + wave * kScr);
+    float *tail = scr0 + 4 * kScr;                           // [zero float4][partial sums [4][64] float4]
+    const int COLS = n_mels;
+    const int64_t first_frame = (int64_t)c0 * FPW;
+    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)HOP;   // the workgroup's sample run (ring blocks count from here)
+    float *out_chunk = out + first_frame * COLS;
+    int frames_left = (int)(n_frames - first_frame);
+    const int out_stride = FPW * COLS;
+
+    // blocks [have, need_end) of the workgroup's sample run into their ring slots; wave w moves blocks have + w,
+    // have + w + 4, ..  Returns the number of DMA instructions this wave issued.
+    int have = 0;
+    // (per-lane addresses from opaque copies of the lane index: as loop invariants they would hold registers the
+    // resident weights need)
+    auto ring_dma = [&](int need_end) {
+        int issued = 0;
+        int ld = lane;
+        asm volatile("" : "+v"(ld));
+        const float *src_wg = src_chunk + 4 * ld;
+        for (int b = have + wave; b < need_end; b += 4, ++issued)
+            lds_dma_16(src_wg + 256 * b, smem + 256 * (b % RB));
+        if (need_end > have)
+            have = need_end;
+        return issued;
+    };
+    const int run_frames = (c1 - c0) * 4 < frames_left ? (c1 - c0) * 4 : frames_left;
+    auto blocks_end = [&](int ci) {
+        const int left = run_frames - 4 * ci;
+        return left <= 0 ? have : 8 * ci + 2 * ((left < 4 ? left : 4) - 1) + 8;
+    };
+    for (int k = 0; k < DEPTH; ++k)
+        ring_dma(blocks_end(k));
+
+    // resident per-lane constants: the window, the pass-A / pass-B twiddles and the mel weights of this wave's quarter of
+    // the filterbank; the combine and split twiddles (2 x 16 registers) are fetched per frame from the plan's float4
+    // tables (the same 8 KB for every wave of the chip: L1 resident) - with them resident the weights do not fit 168
+    // registers, and a per-wave weight table fetched per chunk instead costs 18 us per launch (28 KB per workgroup and
+    // chunk out of the L2)
+    v4f win[8];
+    v2f twA[8], twB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
+                     tab[(4 * j + 3) * 64 + lane]};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
+        twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
+    }
+    const float *ct4 = tab + kWave2048Rows * 64 + 8 * 64 * 4;     // [4][64] float4 of combine twiddle pairs, [4][64] of split pairs
+    const float *wtab = mel_tab + wave * kMelMfmaWaveDwords2048;
+    v4f w[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s)
+        w[s] = reinterpret_cast<const v4f *>(wtab)[64 * s + lane];
+    const unsigned *words = reinterpret_cast<const unsigned *>(wtab + SMAX * 64 * 4);
+    if (tid < 4)
+        tail[tid] = 0.0f;                    // the zero slot of the slice sums (visible behind the first barrier)
+
+    int dma_prev = 0;                        // DMA instructions of the last round
+    for (int c = c0; c < c1; ++c) {
+        // the blocks of this chunk were issued two DMA rounds ago and have landed (the fetch waits of the previous chunk's
+        // frame cover them: vmcnt retires in order); behind them sit the two DMA instructions of the last round and the row
+        // store of the previous chunk, which stay in flight (fewer DMA instructions: a plain wait)
+        if (c - c0 < 2 || dma_prev != 2)
+            wait_vmcnt_le<0>();
+        else
+            wait_vmcnt_le<1 + 2>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();        // T: chunk c has landed; every wave is done with the rows of chunk c - 1
+        __builtin_amdgcn_s_setprio((AA_MELP_PRIO2048 / 1000) % 10);
+        const int nf = frames_left < FPW ? frames_left : FPW;
+        if (wave < nf) {
+            const int t = wave;
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            v2f *e1_wr = scr + 66 * (le & 7) + (le >> 3);
+            const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (le & 7) + 66 * (le >> 3));
+            v2f e[8], o[8];
+            {
+                // frame t starts at block 8 (c - c0) + 2 t; read j is block + j
+                const int s0 = (8 * (c - c0) + 2 * t) % RB;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
+                    const v4f sx = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane] * win[j];
+                    e[j] = v2f{sx.x, sx.y};
+                    o[j] = v2f{sx.z, sx.w};
+                }
+            }
+            fft512_pass_a(e, twA);
+            fft512_exchange1(e, e1_wr, e1_rd);
+            fft512_pass_a(o, twA);
+            fft512_exchange1(o, e1_wr, e1_rd);
+            __builtin_amdgcn_s_setprio((AA_MELP_PRIO2048 / 100) % 10);
+            fft512_pass_bc(e, twB);
+            int lt = lane;
+            asm volatile("" : "+v"(lt));     // (opaque: the table addresses are not hoisted out of the chunk loop)
+            v2f wc[8], tws[8];
+            {
+                // combine twiddles of this frame: in flight during passes B and C of the odd half
+                const v4f *cp = reinterpret_cast<const v4f *>(ct4) + lt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f q = cp[64 * j];
+                    wc[2 * j] = v2f{q.x, q.y};
+                    wc[2 * j + 1] = v2f{q.z, q.w};
+                }
+            }
+            fft512_pass_bc(o, twB);
+            // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
+            v2f zl[8], zh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v2f tt = pk_cmul(o[j], wc[j]);
+                zl[j] = e[j] + tt;
+                zh[j] = e[j] - tt;
+            }
+            {
+                // split twiddles: in flight during the strip round trip
+                asm volatile("" : "+v"(lt));
+                const v4f *sp = reinterpret_cast<const v4f *>(ct4) + 4 * 64 + lt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f q = sp[64 * j];
+                    tws[2 * j] = v2f{q.x, q.y};
+                    tws[2 * j + 1] = v2f{q.z, q.w};
+                }
+            }
+            // strip[i] = Z[512 + i], i = 0..511; strip[512] = Z[1024] := Z[0]
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                scr[lane + 64 * j] = zh[j];
+            if (lane == 0)
+                scr[512] = zl[0];
+            __builtin_amdgcn_wave_barrier();
+            v2f prt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                prt[j] = scr[512 - (lane + 64 * j)];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_setprio((AA_MELP_PRIO2048 / 10) % 10);
+            v2f pw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v2f ee = pk_add_conj(zl[j], prt[j]), oo = pk_sub_conj(zl[j], prt[j]);
+                v2f tt = pk_cmul(oo, tws[j]);
+                const v2f re = pk_sum_diff_re(ee, tt), im = pk_sum_diff_im(ee, tt);
+                pw[j] = im * im + re * re;
+            }
+            const v2f z512 = zh[0];                    // lane 0: Z[512]; X[512] = 2 conj(Z[512])
+            const float m512 = bin_value<kPower>(2.0f * z512.x, 2.0f * z512.y, log_floor);
+            float *lrow = reinterpret_cast<float *>(scr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lrow[lane + 64 * j] = pw[j].x;
+                lrow[1024 - lane - 64 * j] = pw[j].y;
+            }
+            if (lane == 0)
+                lrow[512] = m512;
+            // the row's last float4 piece is read whole (bin 1024 + three floats with zero weights): keep those finite
+            if (lane < 3)
+                lrow[1025 + lane] = 0.0f;
+        }
+        // ---- the mel contraction of the chunk's four frames ----
+        int ln = lane;
+        asm volatile("" : "+v"(ln));         // (opaque: per-lane addresses are not hoisted out of the chunk loop)
+        unsigned m_off = words[ln], m_emit = words[64 + ln];         // (two L1 hits per chunk instead of two registers)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(m_off), "+v"(m_emit)::"memory");
+        // The LDS-DMA of the chunk after next goes out HERE, behind every fetch of this chunk (twiddles, the two words above):
+        // vmcnt retires in order, so a wait for a fetch issued behind a DMA would wait for the DMA's HBM round trip
+        dma_prev = ring_dma(blocks_end(c - c0 + DEPTH));
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();        // B1: the four power rows are written
+        __builtin_amdgcn_s_setprio(AA_MELP_PRIO2048 % 10);
+        const v4f *q = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(scr0 + (ln & 3) * kScr) + m_off);
+        v4f b[SMAX];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            b[s] = q[s];
+        v4f d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = d0;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {     // (a step past n_steps has zero weights: it is skipped, wave-uniform)
+            if (s < n_steps) {
+                d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s].x, b[s].x, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s].y, b[s].y, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s].z, b[s].z, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[s].w, b[s].w, d1, 0, 0, 0);
+            }
+        }
+        // partial sums of (block, frame): lane = (block, frame j)
+        v4f *p4 = reinterpret_cast<v4f *>(tail + 4) + wave * 64;
+        p4[ln] = d0 + d1;
+        __builtin_amdgcn_wave_barrier();
+        // lanes re-labelled (quad slot = lane / 8, frame f = (lane / 2) % 4, half = lane % 2): each lane adds the slices
+        // (consecutive blocks) of two of its quad's mels - all 64 lanes busy for 8 quads, two logs per lane
+        unsigned em = m_emit;
+        asm volatile("" : "+v"(em));
+        const int ns = (int)(em & 31u), blk0 = (int)((em >> 5) & 15u);
+        const int hmax = __builtin_amdgcn_readfirstlane((int)(em >> 24) & 31);
+        const int f = (ln >> 1) & 3;
+        const v2f *src = reinterpret_cast<const v2f *>(p4 + 4 * blk0 + f) + (ln & 1);
+        const v2f *z2 = reinterpret_cast<const v2f *>(tail);
+        v2f m2 = {0.0f, 0.0f};
+        for (int h0 = 0; h0 < hmax; h0 += 4) {
+            const v2f t0 = *(h0 + 0 < ns ? src + 8 * (h0 + 0) : z2);
+            const v2f t1 = *(h0 + 1 < ns ? src + 8 * (h0 + 1) : z2);
+            const v2f t2 = *(h0 + 2 < ns ? src + 8 * (h0 + 2) : z2);
+            const v2f t3 = *(h0 + 3 < ns ? src + 8 * (h0 + 3) : z2);
+            m2 += (t0 + t1) + (t2 + t3);
+        }
+        if (ns != 0) {
+            const int q2 = (int)((em >> 9) & 31u) * 4 + 2 * (ln & 1);
+            v2f l2;
+            l2.x = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m2.x, log_floor));
+            l2.y = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(m2.y, log_floor));
+            // rows of n_mels floats (a multiple of 4, 16-byte-aligned buffer): one dwordx2 per (quad half, frame).  (Measured
+            // and rejected: the pairs parked in LDS and stored half a chunk later as one coalesced row per wave, so that no
+            // fetch wait of the next frame covers a fresh store - 85.0 us against 82.6; whatever the store's position, a
+            // timing-only build without it runs at 75.5.)
+            if (f < nf)                                      // (nontemporal: 81.6 us against 83.0)
+                __builtin_nontemporal_store(l2, reinterpret_cast<v2f *>(out_chunk + __mul24(f, COLS) + q2));
+        }
+        out_chunk += out_stride;
+        frames_left -= FPW;
+    }
+}
+
 // -------------------------------- several frames per wave, n_fft = 128, 256 and 512 --
 // 256/64 is the onset geometry of the reference (src/analysis/onset.rs:122-123); 512 shares the
 // structure (and 128, with no DPP stage at all).  M = n_fft/2 complex points per frame on LPF = M/8
@@ -4221,6 +4489,22 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
     return hipGetLastError();
 }
 
+// kLogMelM at hop 512: stft_wave2048_mel_kernel (arguments validated by launch_wave2048)
+static hipError_t launch_wave2048_mel(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames,
+                                      float log_floor, hipStream_t stream, const float *mel_tab, const MelSched &sch,
+                                      const Channels &ch)
+{
+    const int64_t chunks = (n_frames + 3) / 4;
+    const size_t lds = wave2048_mel_lds_bytes();
+    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
+    if (cached_grid == 0)
+        cached_grid = persistent_grid(stft_wave2048_mel_kernel<kLogMelM>, lds);
+    const dim3 grid(channel_grid(cached_grid, chunks, ch.n)), block(kWave1024Threads);
+    hipLaunchKernelGGL((stft_wave2048_mel_kernel<kLogMelM>), grid, block, lds, stream, x, out, table, frame_begin, n_frames,
+                       chunks, log_floor, mel_tab, sch.n_mels, sch.n_steps, ch.n, ch.in_stride, ch.out_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par, const MelSched *sched,
@@ -4236,6 +4520,12 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
         return hipErrorInvalidValue;
     if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelStreamMaxSteps))
         return hipErrorInvalidValue;
+    if (out_kind == kLogMelM) {
+        if (!mel_par || hop != 512 || frames_per_wg != 4 || sch.n_steps < 1 || sch.n_steps > kMelMfmaSteps2048 ||
+            sch.n_mels < 16 || sch.n_mels > kMelMaxMels || (sch.n_mels & 3) || (reinterpret_cast<uintptr_t>(out) & 15u))
+            return hipErrorInvalidValue;
+        return launch_wave2048_mel(x, out, table, frame_begin, n_frames, log_floor, stream, mel_par, sch, ch);
+    }
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
