@@ -459,6 +459,52 @@ def test_mfcc_sine_and_chirp(aa, oracle_mod, torch_mod):
         assert nerr(got, L @ dct.T).max() < 1e-5
 
 
+def test_mfcc_error_terms_and_chirp_sweep(aa, oracle_mod, torch_mod):
+    """configs[4] again, robustly (the review's question: 9.4e-6 against a 1e-5 bar - which term, and does another chirp
+    rate or dither seed fail?).  The distance to the float64 definition is taken apart per case:
+      e_post   product MFCC rows against float64 post-ops (mel sums, 10 log10, DCT-II) of the PRODUCT's OWN power rows -
+               everything the kernel does behind the FFT: f32 mel sums on the matrix cores, v_log_f32, the f32 MFMA DCT;
+      e_fft    the same float64 post-ops fed with the product's power rows against the float64 definition - the f32 FFT;
+      e_cpu    .. fed with the C restatement's f32 power rows (the reference's arithmetic type on the CPU) - what any
+               correct f32 STFT yields under this metric.
+    Finding (profiles/r04_mfcc_error_terms.txt): e_post ~2e-7, forty times below the bar; e_fft carries all of it - the
+    rounding floor of a 1024-point f32 transform in mel bands 130 dB below the frame's peak (narrow low-frequency
+    filters that catch one bin near an edge) - and single frames of other seeds / rates reach 2e-5, on the CPU path as
+    on the product (both transforms go through the half-length complex FFT of realfft's even-length path, whose split
+    leaves an eps-sized image of a strong bin k at bin N/2 - k: 8e-8 of the peak in either implementation, fifteen
+    times the noise elsewhere).  So the bar cannot be held per frame by ANY f32 pipeline of the reference's structure;
+    what is asserted: the kernel-side terms <= 1e-6 always; 99 % of the frames of every case within 1e-5; and, over the
+    21 cases as a set, the product no further from the definition than the CPU f32 path (median within 1.5 x, worst
+    case within 2 x)."""
+    sr, n, hop, n_mels, n_mfcc = 48000, 1024, 256, 128, 40
+    tr = oracle_mod.truth
+    fb, dct = tr.mel_filterbank(sr, n, n_mels), tr.dct2_ortho(n_mfcc, n_mels)
+    win = oracle_mod.hann_window(n)
+    post = lambda P: (10.0 * np.log10(np.maximum(P @ fb.T, 1e-10))) @ dct.T
+    plan = aa.Stft(n, hop, output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc)
+    pplan = aa.Stft(n, hop, output="power")
+    worst = []
+    for f1 in (3000.0, 6000.0, 8000.0, 12000.0, 16000.0, 20000.0, 23000.0):
+        for seed in (1, 2, 3):
+            rng = np.random.default_rng(seed)
+            x = (aa.signals.chirp(50.0, f1, 4 * sr) + (1e-3 * rng.standard_normal(4 * sr)).astype(np.float32)).astype(np.float32)
+            xd = torch_mod.from_numpy(x).cuda()
+            got = plan(xd).cpu().numpy().astype(np.float64)
+            pw = pplan(xd).cpu().numpy().astype(np.float64)
+            ref = post(np.abs(tr.stft_complex(x, n, hop, win)) ** 2)
+            cpu = post(np.abs(oracle_mod.stft(x, n, hop, kind="complex").astype(np.complex128)) ** 2)
+            e_post, e_fft, e_cpu, e_all = nerr(got, post(pw)), nerr(post(pw), ref), nerr(cpu, ref), nerr(got, ref)
+            assert e_post.max() < 1e-6, (f1, seed, e_post.max())
+            assert np.quantile(e_all, 0.99) < 1e-5, (f1, seed, np.quantile(e_all, 0.99))
+            worst.append((e_all.max(), e_cpu.max(), e_post.max(), e_fft.max()))
+    w = np.array(worst)
+    print("per case max: product", np.array2string(w[:, 0], precision=2), "cpu f32", np.array2string(w[:, 1], precision=2))
+    # the two f32 paths are equally far from the definition (independent rounding noise: compare the 21 cases as a set)
+    assert np.median(w[:, 0]) < 1.5 * np.median(w[:, 1]) + 1e-6, (np.median(w[:, 0]), np.median(w[:, 1]))
+    assert w[:, 0].max() < 2.0 * w[:, 1].max() + 2e-6, (w[:, 0].max(), w[:, 1].max())
+    assert w[:, 2].max() < 1e-6
+
+
 def test_mel_argument_errors(aa):
     with pytest.raises(aa.AaError):
         aa.Stft(1024, 256, output="logmel", n_mels=0)
