@@ -120,6 +120,7 @@ SIGNATURES = {
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "aa_onset_gates_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "aa_tuner_pitches_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
@@ -129,7 +130,8 @@ SIGNATURES = {
                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p]),
     "aa_onset_gates_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
-                                                   ctypes.c_int32] + [ctypes.c_void_p] * 12),
+                                                   ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] +
+                                    [ctypes.c_void_p] * 9),
     "aa_tuner_floor_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_void_p]),

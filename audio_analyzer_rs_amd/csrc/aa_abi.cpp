@@ -1639,9 +1639,9 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
 }
 
 int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bins, const float *flux_dev,
-                          const float *energy_dev, const float *global_floor_dev, float *state_dev,
-                          int32_t initialized, float *out_flux_dev, float *out_ema_dev,
-                          float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                          const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                          int32_t calibrated, float *state_dev, int32_t initialized, float *out_flux_dev,
+                          float *out_ema_dev, float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
                           float *out_velocity_dev, void *stream)
 {
     if (!mags_dev || !flux_dev || !energy_dev || !global_floor_dev || !state_dev || !out_flux_dev ||
@@ -1652,7 +1652,8 @@ int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bin
         return fail(AA_ERR_UNSUPPORTED, "aa_onset_gates_device: n_bins > 4160 is not built (got %d)", n_bins);
     AA_HIP(aa::launch_onset_gates(mags_dev, flux_dev, energy_dev, global_floor_dev, state_dev, initialized,
                                   n_frames, n_bins, out_flux_dev, out_ema_dev, out_excess_dev, out_count_dev,
-                                  out_flags_dev, out_velocity_dev, (hipStream_t)stream));
+                                  out_flags_dev, out_velocity_dev, (hipStream_t)stream, nullptr, nullptr, 1,
+                                  suppress_dev, calibrated));
     return AA_OK;
 }
 
@@ -1697,10 +1698,11 @@ int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offse
 
 int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
                                 int64_t n_frames_total, int32_t n_bins, const float *flux_dev,
-                                const float *energy_dev, const float *global_floor_dev, float *state_dev,
-                                const int32_t *initialized_dev, float *out_flux_dev, float *out_ema_dev,
-                                float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
-                                float *out_velocity_dev, void *stream)
+                                const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                                int32_t calibrated, float *state_dev, const int32_t *initialized_dev,
+                                float *out_flux_dev, float *out_ema_dev, float *out_excess_dev,
+                                int32_t *out_count_dev, uint8_t *out_flags_dev, float *out_velocity_dev,
+                                void *stream)
 {
     if (!mags_dev || !frame_offsets_dev || !flux_dev || !energy_dev || !global_floor_dev || !state_dev ||
         !out_flux_dev || !out_ema_dev || !out_excess_dev || !out_count_dev || !out_flags_dev ||
@@ -1711,7 +1713,7 @@ int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offs
     AA_HIP(aa::launch_onset_gates(mags_dev, flux_dev, energy_dev, global_floor_dev, state_dev, 0, n_frames_total,
                                   n_bins, out_flux_dev, out_ema_dev, out_excess_dev, out_count_dev, out_flags_dev,
                                   out_velocity_dev, (hipStream_t)stream, frame_offsets_dev, initialized_dev,
-                                  n_streams));
+                                  n_streams, suppress_dev, calibrated));
     return AA_OK;
 }
 

@@ -271,7 +271,7 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
                               int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream,
                               const int64_t *offsets = nullptr, const int32_t *init_flags = nullptr,
-                              int n_streams = 1);
+                              int n_streams = 1, const uint8_t *suppress = nullptr, int calibrated = 1);
 hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
                                 float bin_width, float min_freq, float max_freq, float *out_freq,
                                 float *out_score, int32_t *out_count, hipStream_t stream);

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
     const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
     int n_bins, int frames_per_block, float *__restrict__ out_flux, float *__restrict__ out_ema,
     float *__restrict__ out_excess, int32_t *__restrict__ out_count, uint8_t *__restrict__ out_flags,
-    float *__restrict__ out_velocity, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags)
+    float *__restrict__ out_velocity, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags,
+    const uint8_t *__restrict__ suppress, int calibrated)
 {
 #pragma clang fp contract(off)
     extern __shared__ float gate_lds[];
@@ -231,6 +232,8 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         out_count += f0;
         out_flags += f0;
         out_velocity += f0;
+        if (suppress)
+            suppress += f0;
         state += (int64_t)blockIdx.x * (n_bins + 3);
         initialized = init_flags ? init_flags[blockIdx.x] : 0;
     }
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         const bool mine = lane < nfb;
         const float in_flux = mine ? flux[t0 + lane] : 0.0f, in_energy = mine ? energy[t0 + lane] : 0.0f;
         const float in_gf = mine ? global_floor[t0 + lane] : 0.0f;
+        const int in_sup = (mine && suppress) ? (int)suppress[t0 + lane] : 0;
         float o_flux = 0.0f, o_ema = 0.0f, o_exc = 0.0f, o_vel = 0.0f;
         int o_count = 0, o_flags = 0;
         // this frame's magnitudes; the next frame's are read from LDS one iteration ahead
@@ -337,7 +341,10 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
             const bool burst_onset = mx > 3.0f && count >= 3;
             const bool detected = flux_onset && burst_onset;
             const bool rising = frame_energy > ema * 1.5f;
-            const bool fired = detected && rising && since >= 3;
+            // onset.rs:393-440: a detected onset inside the metronome's tick guard is dropped, and before the latency
+            // calibration has completed nothing fires (both supplied by the caller: they depend on the transport)
+            const bool tick = detected && __builtin_amdgcn_readlane(in_sup, i) != 0;
+            const bool fired = detected && !tick && rising && since >= 3 && calibrated != 0;
             float vel = fmaxf(current_flux, mx * 5.0f) / 50.0f;
             vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
             if (fired || (detected && since < 3))
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
                 o_vel = vel;
                 o_count = count;
                 o_flags = (int)flux_onset | ((int)burst_onset << 1) | ((int)detected << 2) | ((int)rising << 3) |
-                          ((int)fired << 4);
+                          ((int)fired << 4) | ((int)tick << 5);
             }
 #pragma unroll
             for (int j = 0; j < BPL; ++j)
@@ -391,6 +398,258 @@ constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
 // PREF (n_bins <= 64 * 17, the tuner's 1025 included): the frame's two rows come in as 2 x 17 loads issued back to back into
 // registers - the rows of the block's NEXT frame while the current one is scored - instead of a loop of dependent
 // load -> LDS store pairs (17 serialised global round trips per frame: two thirds of the kernel's wave cycles were that wait).
+// onset_gates_split_kernel (r4): the same gate chain for ONE stream per workgroup with the recurrences taken apart, so
+// that a single live stream (the reference's shape: onset.rs runs one) no longer walks its frames in one wave at 0.7 us
+// each.  The per-bin floor recurrence (onset.rs:311-332) is independent per bin and feeds the frame only through the
+// burst count and the largest excess ratio; the scalar recurrences (energy EMA :345-350, FluxTracker :66-83, frame gate
+// :531-535) need only those two numbers.  Five waves, three phases, a block of kGateT frames apart each:
+//   waves 0-2  one lane per bin (<= 192 bins): the floor recurrence of block b, the bin's kGateT magnitudes in registers
+//              (the next block's prefetched from global memory), the ratio of every (frame, bin) into LDS
+//   wave 3     block b - 1: lanes = (frame, half of the bins) walk their column of ratios: count of ratios above
+//              BIN_BURST_RATIO and their maximum (order-free, so bit-identical to the sequential loop)
+//   wave 4     block b - 2: everything per frame that is no recurrence in the lanes (silence gate, burst trigger,
+//              velocity), then the three scalar chains frame by frame
+// One workgroup barrier per block.  Every f32 operation of a bin / of the chain is the reference's, in its order
+// (fp contract off): the outputs are bit-identical to onset_gates_kernel and to the C restatement.
+constexpr int kGateT = 32;
+__global__ __launch_bounds__(320) void onset_gates_split_kernel(
+    const float *__restrict__ mags, const float *__restrict__ flux, const float *__restrict__ energy,
+    const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
+    int n_bins, float *__restrict__ out_flux, float *__restrict__ out_ema,
+    float *__restrict__ out_excess, int32_t *__restrict__ out_count, uint8_t *__restrict__ out_flags,
+    float *__restrict__ out_velocity, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags,
+    const uint8_t *__restrict__ suppress, int calibrated)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float gate_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (offsets) {
+        const int64_t f0 = offsets[blockIdx.x];
+        n_frames = offsets[blockIdx.x + 1] - f0;
+        mags += f0 * n_bins;
+        flux += f0;
+        energy += f0;
+        global_floor += f0;
+        out_flux += f0;
+        out_ema += f0;
+        out_excess += f0;
+        out_count += f0;
+        out_flags += f0;
+        out_velocity += f0;
+        if (suppress)
+            suppress += f0;
+        state += (int64_t)blockIdx.x * (n_bins + 3);
+        initialized = init_flags ? init_flags[blockIdx.x] : 0;
+    }
+    // rows of the ratio image: n_bins columns + a spare one the lanes without a bin write to (no per-frame lane
+    // masks), an odd stride (the column walk of wave 3 is bank-conflict free)
+    const int stride = (n_bins + 1) | 1;
+    float *ratio = gate_lds;                         // [2][kGateT][stride]
+    int *cnts = reinterpret_cast<int *>(gate_lds + 2 * kGateT * stride);    // [2][kGateT]
+    float *maxs = reinterpret_cast<float *>(cnts + 2 * kGateT);            // [2][kGateT]
+    const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
+    const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
+    const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
+    const int64_t n_blocks = (n_frames + kGateT - 1) / kGateT;
+
+    // ---- state of the three roles ----
+    const int bin = 64 * wave + lane;
+    const bool valid = wave < 3 && bin < n_bins;
+    const int col = valid ? bin : n_bins;            // (the spare column)
+    float fl = valid ? state[bin] : 1.0f;
+    float cur[kGateT], nxt[kGateT];
+    float cur_gf = 0.0f, nxt_gf = 0.0f;              // lane i: global_floor of frame i of the block (read by readlane)
+    auto fetch = [&](int64_t b, float (&dst)[kGateT], float &gfv) {
+        const int64_t t0 = b * kGateT;
+        if (t0 + kGateT <= n_frames) {               // (a full block: no per-frame bounds)
+            const float *m = mags + t0 * n_bins + (valid ? bin : 0);
+#pragma unroll
+            for (int i = 0; i < kGateT; ++i)
+                dst[i] = m[(int64_t)i * n_bins];
+        } else {
+#pragma unroll
+            for (int i = 0; i < kGateT; ++i)
+                dst[i] = (valid && t0 + i < n_frames) ? mags[(t0 + i) * n_bins + bin] : 0.0f;
+        }
+        gfv = (lane < kGateT && t0 + lane < n_frames) ? global_floor[t0 + lane] : 0.0f;
+    };
+    // wave 4: the per-frame inputs of a block, fetched a step ahead as well
+    float b_flux = 0.0f, b_energy = 0.0f, n_flux = 0.0f, n_energy = 0.0f;
+    int b_sup = 0, n_sup = 0;
+    auto fetch_b = [&](int64_t b, float &vf, float &ve, int &vs) {
+        const int64_t t = b * kGateT + lane;
+        const bool in = lane < kGateT && t < n_frames;
+        vf = in ? flux[t] : 0.0f;
+        ve = in ? energy[t] : 0.0f;
+        vs = (in && suppress) ? (int)suppress[t] : 0;
+    };
+    float ema = 0.0f, thr = 0.0f;
+    int since = 4;
+    if (initialized) {
+        ema = state[n_bins];
+        thr = state[n_bins + 1];
+        since = __float_as_int(state[n_bins + 2]);
+    }
+    if (wave < 3 && n_blocks > 0) {
+        fetch(0, cur, cur_gf);
+        if (!initialized)                            // onset.rs:304-309: the floors start at the first frame's magnitudes
+            fl = fmaxf(cur[0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), 0)));
+    }
+    if (wave == 4 && n_blocks > 0)
+        fetch_b(0, b_flux, b_energy, b_sup);
+
+    // one frame of one bin (onset.rs:311-332), branch-free: the three candidate floors, two selects
+    auto bin_step = [&](float mag, float gf) {
+        const float floor_eps = fmaxf(gf, 0.01f);
+        const float r = mag / fmaxf(fl, floor_eps);
+        const float d = mag - fl;
+        const float burst_f = mag * FLOOR_OVERCOMPENSATE, rise_f = fl + FLOOR_RISE * d, decay_f = fl + FLOOR_DECAY * d;
+        const float slow = mag > fl ? rise_f : decay_f;
+        fl = r > BIN_BURST_RATIO ? burst_f : slow;
+        return r;
+    };
+
+    for (int64_t step = 0; step < n_blocks + 2; ++step) {
+        if (wave < 3) {
+            // ---- per-bin floor recurrence of block `step` ----
+            if (step < n_blocks) {
+                if (step + 1 < n_blocks)
+                    fetch(step + 1, nxt, nxt_gf);    // in flight while this block is walked
+                const int64_t t0 = step * kGateT;
+                const int nfb = (int)((n_frames - t0) < kGateT ? (n_frames - t0) : kGateT);
+                float *rb = ratio + (step & 1) * kGateT * stride + col;
+                if (nfb == kGateT) {
+#pragma unroll
+                    for (int i = 0; i < kGateT; ++i)
+                        rb[i * stride] = bin_step(cur[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), i)));
+                } else {
+                    for (int i = 0; i < nfb; ++i) {
+                        float mag = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < kGateT; ++j)
+                            mag = j == i ? cur[j] : mag;
+                        rb[i * stride] = bin_step(mag, __shfl(cur_gf, i));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kGateT; ++i)
+                    cur[i] = nxt[i];
+                cur_gf = nxt_gf;
+            }
+        } else if (wave == 3) {
+            // ---- burst count and largest excess of every frame of block `step - 1` ----
+            if (step >= 1 && step <= n_blocks) {
+                const int pb = (int)((step - 1) & 1);
+                const int i = lane & 31, half = lane >> 5;
+                const int nbh = (n_bins + 1) >> 1;
+                const int k0 = half ? nbh : 0, k1 = half ? n_bins : nbh;
+                const float *colp = ratio + pb * kGateT * stride + i * stride;
+                int count = 0;
+                float mx = 0.0f;
+                int k = k0;
+                for (; k + 8 <= k1; k += 8) {        // eight reads in flight
+                    float r[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        r[j] = colp[k + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        count += r[j] > BIN_BURST_RATIO ? 1 : 0;
+                        mx = r[j] > mx ? r[j] : mx;
+                    }
+                }
+                for (; k < k1; ++k) {
+                    const float r = colp[k];
+                    count += r > BIN_BURST_RATIO ? 1 : 0;
+                    mx = r > mx ? r : mx;
+                }
+                count += __shfl_xor(count, 32);
+                const float other = __shfl_xor(mx, 32);
+                mx = other > mx ? other : mx;
+                if (half == 0) {
+                    cnts[pb * kGateT + i] = count;
+                    maxs[pb * kGateT + i] = mx;
+                }
+            }
+        } else {
+            // ---- the frame's gates and the scalar chains of block `step - 2` ----
+            if (step >= 2) {
+                const int64_t b = step - 2, t0 = b * kGateT;
+                const int pb = (int)(b & 1);
+                const int nfb = (int)((n_frames - t0) < kGateT ? (n_frames - t0) : kGateT);
+                const bool mine = lane < nfb;
+                const int count = mine ? cnts[pb * kGateT + lane] : 0;
+                const float mx = mine ? maxs[pb * kGateT + lane] : 0.0f;
+                float v_flux = b_flux;
+                const float v_energy = b_energy;
+                const int v_sup = b_sup;
+                if (b + 1 < n_blocks)
+                    fetch_b(b + 1, n_flux, n_energy, n_sup);     // in flight while this block's chains run
+                // per frame, no recurrence (lane = frame): silence gate, burst trigger, velocity (onset.rs:336-338, 358,
+                // 381-382) and the products the two memories may pick from (the reference's own operands: x * (1 - memory))
+                if (count < 2)
+                    v_flux = 0.0f;
+                const int bo_l = (mx > 3.0f && count >= 3) ? 1 : 0;
+                float vel = fmaxf(v_flux, mx * 5.0f) / 50.0f;
+                vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
+                const float e_rise = v_energy * (1.0f - ENERGY_EMA_RISE), e_dec = v_energy * (1.0f - ENERGY_EMA_DECAY);
+                const float f_rise = v_flux * (1.0f - rise_memory), f_dec = v_flux * (1.0f - decay_memory);
+                float o_ema = 0.0f;
+                int o_flags = 0;
+                auto lane_f = [&](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
+                auto chain = [&](int i) {
+                    const float current_flux = lane_f(v_flux, i), frame_energy = lane_f(v_energy, i);
+                    const bool bo = __builtin_amdgcn_readlane(bo_l, i) != 0;
+                    const bool sup = __builtin_amdgcn_readlane(v_sup, i) != 0;
+                    const bool up = frame_energy > ema;
+                    ema = ema * (up ? ENERGY_EMA_RISE : ENERGY_EMA_DECAY) + (up ? lane_f(e_rise, i) : lane_f(e_dec, i));
+                    const bool is_onset = current_flux > thr;
+                    thr = thr * (is_onset ? rise_memory : decay_memory) + (is_onset ? lane_f(f_rise, i) : lane_f(f_dec, i));
+                    thr = thr < 0.9f ? 0.9f : thr;
+                    const bool flux_onset = is_onset && current_flux > thr * multiplier;
+                    const bool detected = flux_onset && bo;
+                    const bool rising = frame_energy > ema * 1.5f;
+                    const bool tick = detected && sup;
+                    const bool fired = detected && !tick && rising && since >= 3 && calibrated != 0;
+                    since = (fired || (detected && since < 3)) ? 0 : (since < 0x7fffffff ? since + 1 : since);
+                    const int fl_bits = (int)flux_onset | ((int)bo << 1) | ((int)detected << 2) | ((int)rising << 3) |
+                                        ((int)fired << 4) | ((int)tick << 5);
+                    o_ema = lane == i ? ema : o_ema;
+                    o_flags = lane == i ? fl_bits : o_flags;
+                };
+                if (nfb == kGateT) {
+#pragma unroll
+                    for (int i = 0; i < kGateT; ++i)
+                        chain(i);
+                } else {
+                    for (int i = 0; i < nfb; ++i)
+                        chain(i);
+                }
+                if (mine) {
+                    out_flux[t0 + lane] = v_flux;
+                    out_ema[t0 + lane] = o_ema;
+                    out_excess[t0 + lane] = mx;
+                    out_count[t0 + lane] = count;
+                    out_flags[t0 + lane] = (uint8_t)o_flags;
+                    out_velocity[t0 + lane] = vel;
+                }
+                b_flux = n_flux;
+                b_energy = n_energy;
+                b_sup = n_sup;
+            }
+        }
+        __syncthreads();
+    }
+    if (valid)
+        state[bin] = fl;
+    if (wave == 4 && lane == 0) {
+        state[n_bins] = ema;
+        state[n_bins + 1] = thr;
+        state[n_bins + 2] = __int_as_float(since);
+    }
+}
+
 template <bool PREF>
 __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     const float *__restrict__ mags, const float *__restrict__ eff_floor, int64_t n_frames, int n_bins,
@@ -634,9 +893,10 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
                                                          const int32_t *__restrict__ init_flags)
 {
 #pragma clang fp contract(off)
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= n_bins)
-        return;
+    // (every lane of the wave stays: the frames' global floors are handed round by v_readlane; lanes past the row
+    // walk its last bin and store nothing)
+    const bool valid = (int)(blockIdx.x * 64 + threadIdx.x) < n_bins;
+    const int k = valid ? (int)(blockIdx.x * 64 + threadIdx.x) : n_bins - 1;
     if (offsets) {
         // batch: blockIdx.y walks stream s = frames [offsets[s], offsets[s+1]) of the concatenated arrays
         const int64_t f0 = offsets[blockIdx.y];
@@ -651,9 +911,7 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
     const float VOL_MEMORY = 0.75f, NOTE_RATIO = 1.5f, NOTE_VOL_MAX = 0.15f;
     float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
     bool init = initialized != 0;
-    for (int64_t t = 0; t < n_frames; ++t) {
-        const float mag = mags[t * n_bins + k];
-        const float gf = global_floor[t];
+    auto frame = [&](float mag, float gf) {
         if (!init) {
             fl = fmaxf(mag, gf * 5.0f);
             prev = mag;
@@ -666,17 +924,42 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
             float vn = vol / fmaxf(mag, 0.05f);
             vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
             const bool sustained = above_ratio > NOTE_RATIO && vn < NOTE_VOL_MAX;
-            if (!sustained) {
-                const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn
-                                             : FLOOR_RELEASE;
-                fl = fl + alpha * (mag - fl);
-            }
+            const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn : FLOOR_RELEASE;
+            const float moved = fl + alpha * (mag - fl);
+            fl = sustained ? fl : moved;
         }
-        eff[t * n_bins + k] = fminf(fl, gf * 2.5f);
+        return fminf(fl, gf * 2.5f);
+    };
+    // r4: blocks of kFloorT frames - the bin's magnitudes and the frames' global floors of a block are fetched together
+    // (one memory round trip per block instead of one per frame: a ten-minute stream 26.7 -> ~6 ms), then walked
+    constexpr int kFloorT = 32;
+    const int lane = threadIdx.x;
+    int64_t t = 0;
+    for (; t + kFloorT <= n_frames; t += kFloorT) {
+        float m[kFloorT];
+        const float *mp = mags + t * n_bins + k;
+#pragma unroll
+        for (int i = 0; i < kFloorT; ++i)
+            m[i] = mp[(int64_t)i * n_bins];
+        const float gfv = global_floor[t + (lane & (kFloorT - 1))];      // lane i: frame i of the block
+        float *ep = eff + t * n_bins + k;
+#pragma unroll
+        for (int i = 0; i < kFloorT; ++i) {
+            const float e = frame(m[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gfv), i)));
+            if (valid)
+                ep[(int64_t)i * n_bins] = e;
+        }
     }
-    state[k] = fl;
-    state[n_bins + k] = prev;
-    state[2 * n_bins + k] = vol;
+    for (; t < n_frames; ++t) {
+        const float e = frame(mags[t * n_bins + k], global_floor[t]);
+        if (valid)
+            eff[t * n_bins + k] = e;
+    }
+    if (valid) {
+        state[k] = fl;
+        state[n_bins + k] = prev;
+        state[2 * n_bins + k] = vol;
+    }
 }
 
 // mixed = (sum of the first min(channels, 2) channels) / that count — mod.rs:784-794
@@ -750,12 +1033,23 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
                               const float *global_floor, float *state, int initialized, int64_t n_frames,
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
                               int32_t *out_count, uint8_t *out_flags, float *out_velocity, hipStream_t stream,
-                              const int64_t *offsets, const int32_t *init_flags, int n_streams)
+                              const int64_t *offsets, const int32_t *init_flags, int n_streams,
+                              const uint8_t *suppress, int calibrated)
 {
     if (n_frames <= 0 || n_streams <= 0)
         return hipSuccess;
     if (n_bins < 1 || n_bins > 64 * kGatePrefetchRegs)
         return hipErrorInvalidValue;
+    // few streams of the onset geometry: the recurrences taken apart, one workgroup of five waves per stream (a single
+    // ten-minute stream: 313 -> ~30 ms); many streams already fill the chip with one wave each
+    if (n_bins <= 192 && n_streams < 256) {
+        const int stride = (n_bins + 1) | 1;
+        const size_t lds2 = sizeof(float) * (size_t)(2 * kGateT * stride + 4 * kGateT);
+        hipLaunchKernelGGL(onset_gates_split_kernel, dim3((unsigned)n_streams), dim3(320), lds2, stream, mags, flux, energy,
+                           global_floor, state, initialized, n_frames, n_bins, out_flux, out_ema, out_excess, out_count,
+                           out_flags, out_velocity, offsets, init_flags, suppress, calibrated);
+        return hipGetLastError();
+    }
     int fpb = 64 * kGatePrefetchRegs / n_bins;       // frames per prefetched block, one lane per frame
     if (fpb > 64)
         fpb = 64;
@@ -764,7 +1058,7 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
 #define AA_GATES(B)                                                                                      \
     hipLaunchKernelGGL(onset_gates_kernel<B>, dim3((unsigned)n_streams), dim3(64), lds, stream, mags, flux, \
                        energy, global_floor, state, initialized, n_frames, n_bins, fpb, out_flux, out_ema,  \
-                       out_excess, out_count, out_flags, out_velocity, offsets, init_flags)
+                       out_excess, out_count, out_flags, out_velocity, offsets, init_flags, suppress, calibrated)
     if (bpl <= 3)
         AA_GATES(3);        // 129 bins: the onset geometry (onset.rs:122-125)
     else if (bpl <= 9)

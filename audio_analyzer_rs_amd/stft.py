@@ -234,12 +234,15 @@ def onset_flux(mags, prev_row=None, stream=None, offsets=None):
 ONSET_FLAG_FLUX, ONSET_FLAG_BURST, ONSET_FLAG_DETECTED, ONSET_FLAG_ENERGY_RISING, ONSET_FLAG_FIRED = 1, 2, 4, 8, 16
 
 
-def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offsets=None):
+def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offsets=None, suppress=None,
+                calibrated=True):
     """The onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
     531-535): burst floor, silence gate, energy EMA, FluxTracker, combined trigger, velocity,
-    frames_since_onset gate (calibrated transport, no metronome tick).  All arguments are CUDA
-    tensors: mags float32 [frames, bins]; flux, energy, global_floor float32 [frames].  state:
-    None for a fresh detector, or the [bins + 3] tensor returned by a previous call.
+    frames_since_onset gate.  All arguments are CUDA tensors: mags float32 [frames, bins]; flux,
+    energy, global_floor float32 [frames].  suppress (uint8 [frames], non-zero = inside the
+    metronome's tick guard, onset.rs:393-396; None = never) and calibrated (False = the latency
+    calibration is still running: nothing fires, onset.rs:404-440) are the transport's inputs.
+    state: None for a fresh detector, or the [bins + 3] tensor returned by a previous call.
     offsets (CUDA int64 [n_streams + 1]): independent streams laid end to end, one wave each; state
     is then [n_streams, bins + 3].
     Returns (dict of per-frame tensors, state)."""
@@ -260,17 +263,21 @@ def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offse
         "velocity": torch.empty(nf, dtype=torch.float32, device=mags.device),
     }
     st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
+    if suppress is not None and (suppress.dtype != torch.uint8 or suppress.numel() != nf or not suppress.is_cuda):
+        raise ValueError("suppress must be a CUDA uint8 tensor with one entry per frame")
+    sup = suppress.data_ptr() if suppress is not None else None
     if nf and ns is not None:
         init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
         _lib.check(lib.aa_onset_gates_batch_device(
             mags.data_ptr(), offsets.data_ptr(), ns, nf, nb, flux.data_ptr(), energy.data_ptr(),
-            global_floor.data_ptr(), state.data_ptr(), init.data_ptr(), out["flux"].data_ptr(),
+            global_floor.data_ptr(), sup, 1 if calibrated else 0, state.data_ptr(), init.data_ptr(), out["flux"].data_ptr(),
             out["energy_ema"].data_ptr(), out["max_excess"].data_ptr(), out["burst_count"].data_ptr(),
             out["flags"].data_ptr(), out["velocity"].data_ptr(), st))
     elif nf:
         _lib.check(lib.aa_onset_gates_device(
-            mags.data_ptr(), nf, nb, flux.data_ptr(), energy.data_ptr(), global_floor.data_ptr(),
-            state.data_ptr(), 1 if initialized else 0, out["flux"].data_ptr(), out["energy_ema"].data_ptr(),
+            mags.data_ptr(), nf, nb, flux.data_ptr(), energy.data_ptr(), global_floor.data_ptr(), sup,
+            1 if calibrated else 0, state.data_ptr(), 1 if initialized else 0, out["flux"].data_ptr(),
+            out["energy_ema"].data_ptr(),
             out["max_excess"].data_ptr(), out["burst_count"].data_ptr(), out["flags"].data_ptr(),
             out["velocity"].data_ptr(), st))
     return out, state

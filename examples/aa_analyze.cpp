@@ -216,7 +216,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMemcpy(d_gf, gf.data(), sizeof(float) * (size_t)of, hipMemcpyHostToDevice));
         CHECK_AA(aa_stft_execute_device(onset, d_x, n, 0, of, d_mag, nullptr));
         CHECK_AA(aa_onset_flux_device(d_mag, of, ob, nullptr, d_flux, d_energy, nullptr));
-        CHECK_AA(aa_onset_gates_device(d_mag, of, ob, d_flux, d_energy, d_gf, d_state, 0, d_oflux, d_ema, d_exc,
+        CHECK_AA(aa_onset_gates_device(d_mag, of, ob, d_flux, d_energy, d_gf, nullptr, 1, d_state, 0, d_oflux, d_ema, d_exc,
                                        d_cnt, d_flags, d_vel, nullptr));
         CHECK_HIP(hipMemcpy(flags.data(), d_flags, (size_t)of, hipMemcpyDeviceToHost));
         CHECK_HIP(hipMemcpy(velocity.data(), d_vel, sizeof(float) * (size_t)of, hipMemcpyDeviceToHost));

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 2
+#define AA_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -216,20 +216,28 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
  *             bin_burst_onset = max_excess > 3 && burst_count >= 3; onset_detected (:355-357)
  *             energy_rising = energy > 1.5 ema (:373); velocity (:389-390)
  *             frames_since_onset gate (:402, :531-535)
- * with the transport-dependent parts fixed to "calibrated, no metronome tick nearby":
- * onset_fired = onset_detected && energy_rising && frames_since_onset >= 3.
+ * and the two transport-dependent inputs of the decision (onset.rs:361-371, 385-440), supplied by the caller because
+ * they come from the MusicalTransport, not from the spectrum (ABI version 3):
+ *   suppress_dev  one byte per frame, non-zero = the metronome's nearest tick is closer than the tick guard
+ *                 (tick_dist < TICK_GUARD_S * bpm / 60, :393-396): a detected onset there is dropped; NULL = never
+ *   calibrated    0 = the latency calibration has not completed (:404-440, :361-371): onsets are detected but none
+ *                 fires (the caller watches flags bit 2 for its click and flips the argument when it has its offset)
+ * onset_fired = onset_detected && !suppressed && energy_rising && frames_since_onset >= 3 && calibrated.
  * Inputs: magnitude rows [n_frames x n_bins], flux / frame energy per frame (aa_onset_flux_device),
  * global_floor per frame (= 10^(noise_floor_db/20) * n_bins / 2, onset.rs:299-300).
  * state_dev: n_bins + 3 floats {floors, energy_ema, tracker threshold, frames_since_onset (int
  * bits)}, updated in place; `initialized` = 0 starts a fresh detector.
  * Outputs per frame: gated flux, energy EMA, max_excess, burst count, velocity and
  * flags = flux_onset | bin_burst_onset << 1 | onset_detected << 2 | energy_rising << 3 |
- * onset_fired << 4.  One wave walks the frames in order in the reference's operation order:
- * every output is bit-identical to the sequential f32 evaluation on the same inputs. */
+ * onset_fired << 4 | suppressed_by_tick << 5.  Every f32 operation is the reference's, in its order: all outputs are
+ * bit-identical to the sequential evaluation on the same inputs.  Up to 192 bins (the onset geometry has 129) a stream
+ * runs as one workgroup of five waves with the recurrences taken apart - the per-bin floors one lane per bin, the burst
+ * count / largest excess of a frame as a column walk, the scalar chains in a wave of their own, a block of 32 frames
+ * apart (a ten-minute stream: ~30 ms; one wave walking the frames took 313 ms); wider spectra keep the one-wave form. */
 int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bins, const float *flux_dev,
-                          const float *energy_dev, const float *global_floor_dev, float *state_dev,
-                          int32_t initialized, float *out_flux_dev, float *out_ema_dev,
-                          float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
+                          const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                          int32_t calibrated, float *state_dev, int32_t initialized, float *out_flux_dev,
+                          float *out_ema_dev, float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
                           float *out_velocity_dev, void *stream);
 
 /* ---- tuner front end: per-bin adaptive noise floor (src/audio_io/stft.rs:326-367) ---- */
@@ -280,10 +288,11 @@ int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offse
                                float *flux_dev, float *energy_dev, void *stream);
 int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
                                 int64_t n_frames_total, int32_t n_bins, const float *flux_dev,
-                                const float *energy_dev, const float *global_floor_dev, float *state_dev,
-                                const int32_t *initialized_dev, float *out_flux_dev, float *out_ema_dev,
-                                float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
-                                float *out_velocity_dev, void *stream);
+                                const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                                int32_t calibrated, float *state_dev, const int32_t *initialized_dev,
+                                float *out_flux_dev, float *out_ema_dev, float *out_excess_dev,
+                                int32_t *out_count_dev, uint8_t *out_flags_dev, float *out_velocity_dev,
+                                void *stream);
 int aa_tuner_floor_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
                                 int64_t n_frames_total, int32_t n_bins, const float *global_floor_dev,
                                 float *state_dev, const int32_t *initialized_dev, float *eff_floor_dev,

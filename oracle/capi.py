@@ -60,7 +60,8 @@ class Oracle:
         lib.aao_stream_push.restype = ctypes.c_int64
         lib.aao_onset_flux.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p]
         lib.aao_onset_flux.restype = None
-        lib.aao_onset_gates.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
+        lib.aao_onset_gates.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p,
+                                        ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _f32p,
                                         ctypes.POINTER(ctypes.c_int), _f32p, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8), _f32p]
         lib.aao_onset_gates.restype = None
@@ -241,8 +242,9 @@ def tuner_floor(mags, global_floor, state=None, initialized=False):
     return eff, st, bool(init.value)
 
 
-def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False):
-    """Onset detector logic after the flux (src/analysis/onset.rs:298-371, 531-535), sequential f32.
+def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False, suppress=None, calibrated=True):
+    """Onset detector logic after the flux (src/analysis/onset.rs:298-371, 531-535), sequential f32; suppress
+    (uint8 per frame: inside the metronome's tick guard, :393-396) and calibrated (:404-440) are the transport's inputs.
     Returns (dict of per-frame arrays, state [bins + 3], initialized)."""
     mags = np.ascontiguousarray(mags, dtype=np.float32)
     nf, nb = mags.shape
@@ -255,7 +257,9 @@ def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False)
            "max_excess": np.empty(nf, np.float32), "burst_count": np.empty(nf, np.int32),
            "flags": np.empty(nf, np.uint8), "velocity": np.empty(nf, np.float32)}
     Oracle.get().lib.aao_onset_gates(
-        _ptr(mags), nf, nb, _ptr(flux), _ptr(energy), _ptr(gf), _ptr(st), ctypes.byref(init), _ptr(out["flux"]),
+        _ptr(mags), nf, nb, _ptr(flux), _ptr(energy), _ptr(gf),
+        None if suppress is None else np.ascontiguousarray(suppress, dtype=np.uint8).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+        1 if calibrated else 0, _ptr(st), ctypes.byref(init), _ptr(out["flux"]),
         _ptr(out["energy_ema"]), _ptr(out["max_excess"]),
         out["burst_count"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
         out["flags"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _ptr(out["velocity"]))

@@ -441,14 +441,16 @@ void aao_onset_flux(const float *mags, int64_t n_frames, int n_bins, const float
  * the flux: per-bin "rise-once, suppress" burst floor (:311-332), silence gate (:337-339),
  * energy EMA (:345-350), FluxTracker::update (:66-83, constructed :158 with (1.5, 0.84, 0.89)),
  * combined trigger (:355-357), energy_rising (:373), velocity (:389-390) and the
- * frames_since_onset gate (:402, 531-535).  Offline semantics: transport calibrated and no
- * metronome tick nearby, i.e. onset_fired = onset_detected && energy_rising &&
- * frames_since_onset >= 3.
+ * frames_since_onset gate (:402, 531-535).  The two transport-dependent inputs of the decision are arguments:
+ * suppress[t] != 0 <=> the nearest metronome tick is inside the tick guard (:393-396; NULL = never) and
+ * calibrated == 0 <=> the latency calibration is still running (:361-371, :404-440: nothing fires), i.e.
+ * onset_fired = onset_detected && !suppressed && energy_rising && frames_since_onset >= 3 && calibrated.
  * state: n_bins floors, then energy_ema, tracker threshold, frames_since_onset (int bits).
  * flags: bit0 flux_onset, bit1 bin_burst_onset, bit2 onset_detected, bit3 energy_rising,
- * bit4 onset_fired.  Plain f32 in the reference's operation order (-ffp-contract=off). */
+ * bit4 onset_fired, bit5 suppressed_by_tick.  Plain f32 in the reference's operation order (-ffp-contract=off). */
 void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const float *flux,
-                     const float *energy, const float *global_floor, float *state, int *initialized,
+                     const float *energy, const float *global_floor, const uint8_t *suppress, int calibrated,
+                     float *state, int *initialized,
                      float *out_flux, float *out_ema, float *out_excess, int32_t *out_count,
                      uint8_t *out_flags, float *out_velocity)
 {
@@ -507,7 +509,11 @@ void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const floa
         const int bin_burst_onset = max_bin_excess > 3.0f && bin_burst_count >= 3;
         const int onset_detected = flux_onset && bin_burst_onset;
         const int energy_rising = frame_energy > ema * 1.5f;
-        const int fired = onset_detected && energy_rising && since >= 3;
+        /* onset.rs:393-396: suppressed_by_tick = tick_dist < tick_guard_beats (the transport's figure: an input here);
+         * :402-440: nothing fires before the latency calibration has completed (pre-calibration onsets are ignored or
+         * consumed by the calibration itself; its completion is the caller's to decide: `calibrated`) */
+        const int tick = onset_detected && suppress && suppress[t] != 0;
+        const int fired = onset_detected && !tick && energy_rising && since >= 3 && calibrated != 0;
         float vel = fmaxf(current_flux, max_bin_excess * 5.0f) / 50.0f;
         vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
         if (fired || (onset_detected && since < 3))
@@ -519,7 +525,7 @@ void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const floa
         out_excess[t] = max_bin_excess;
         out_count[t] = bin_burst_count;
         out_flags[t] = (uint8_t)(flux_onset | (bin_burst_onset << 1) | (onset_detected << 2) |
-                                 (energy_rising << 3) | (fired << 4));
+                                 (energy_rising << 3) | (fired << 4) | (tick << 5));
         out_velocity[t] = vel;
     }
     state[n_bins] = ema;

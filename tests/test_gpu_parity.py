@@ -610,6 +610,38 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
     for key in out:
         assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), out[key]), key
     assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32))
+    # the transport's inputs (ABI version 3; onset.rs:393-396, 404-440): a metronome tick guard over every second fired
+    # onset, and a run before the latency calibration has completed - bit for bit against the restatement; an all-zero
+    # mask is the call above
+    fired = np.nonzero(out["flags"].cpu().numpy() & aa.stft.ONSET_FLAG_FIRED)[0]
+    sup = np.zeros(nf, np.uint8)
+    for f in fired[::2]:
+        sup[max(0, f - 2):f + 3] = 1
+    supd = torch_mod.from_numpy(sup).cuda()
+    m_cpu, m_cpu_state = mags.cpu().numpy(), None
+    for kw_gpu, kw_cpu in ((dict(suppress=supd), dict(suppress=sup)), (dict(calibrated=False), dict(calibrated=False)),
+                           (dict(suppress=torch_mod.zeros(nf, dtype=torch_mod.uint8, device="cuda")), dict())):
+        got, gstate = aa.onset_gates(mags, flux, energy, gfd, **kw_gpu)
+        want, wstate, _ = oracle_mod.onset_gates(m_cpu, flux.cpu().numpy(), energy.cpu().numpy(), gf, **kw_cpu)
+        for key in want:
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), (key, list(kw_cpu))
+        assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32))
+    got, _ = aa.onset_gates(mags, flux, energy, gfd, suppress=supd)
+    assert not bool(((got["flags"] & aa.stft.ONSET_FLAG_FIRED).bool() & supd.bool()).any())
+    assert int((got["flags"] & 32).bool().sum()) >= len(fired[::2])
+    # the one-wave form (spectra wider than 192 bins, or >= 256 streams) carries the same inputs: 513 bins
+    mags1k = aa.Stft(1024, 256, output="mag")(xd)
+    f1k, e1k = aa.onset_flux(mags1k)
+    n1k = mags1k.shape[0]
+    gf1k = np.full(n1k, 10.0 ** (-60.0 / 20.0) * 513 / 2.0, np.float32)
+    sup1k = (np.arange(n1k) % 7 < 3).astype(np.uint8)
+    for kw_gpu, kw_cpu in ((dict(suppress=torch_mod.from_numpy(sup1k).cuda()), dict(suppress=sup1k)),
+                           (dict(calibrated=False), dict(calibrated=False))):
+        got, gstate = aa.onset_gates(mags1k, f1k, e1k, torch_mod.from_numpy(gf1k).cuda(), **kw_gpu)
+        want, wstate, _ = oracle_mod.onset_gates(mags1k.cpu().numpy(), f1k.cpu().numpy(), e1k.cpu().numpy(), gf1k, **kw_cpu)
+        for key in want:
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), (key, list(kw_cpu))
+        assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32))
 
 
 def test_batched_streams_equal_per_stream_calls(aa, torch_mod):

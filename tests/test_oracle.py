@@ -157,6 +157,28 @@ def test_onset_gates_restatement(oracle_mod):
     for key in out:
         assert np.array_equal(np.concatenate([o1[key], o2[key]]), out[key]), key
     assert np.array_equal(s2, st)
+    # the transport's inputs (onset.rs:393-396, 404-440).  An all-zero tick mask and calibrated = 1 are the call above.
+    z, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=np.zeros(len(flux), np.uint8), calibrated=True)
+    for key in out:
+        assert np.array_equal(z[key], out[key]), key
+    # a tick guard over every second fired onset: those are detected but dropped (bit 5), and - exactly as in the
+    # reference - frames_since_onset is NOT reset by a dropped onset unless it is below 3 (:531-535), so the onset's
+    # later frames may fire instead: every frame that fired without the mask and sits under it must not fire now
+    sup = np.zeros(len(flux), np.uint8)
+    for f in fired[::2]:
+        sup[max(0, f - 2):f + 3] = 1
+    m, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=sup)
+    mf = m["flags"]
+    assert not np.any((mf & 16) & (sup.astype(bool) * 16))
+    assert np.all((mf[fired[::2]] & 32) != 0) and np.all((mf[fired[1::2]] & 16) != 0)
+    assert np.array_equal((mf & 32) != 0, ((mf & 4) != 0) & (sup != 0))
+    # the parts of the decision in front of the tick test do not depend on it
+    for key in ("flux", "energy_ema", "max_excess", "burst_count", "velocity"):
+        assert np.array_equal(m[key], out[key]), key
+    assert np.array_equal(mf & 15, out["flags"] & 15)
+    # before the calibration has completed: everything detected, nothing fired
+    u, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, calibrated=False)
+    assert not np.any(u["flags"] & 16) and np.array_equal(u["flags"] & 15, out["flags"] & 15)
 
 
 def _chord_signal(seconds=3.0, sr=48000, seed=3):
