@@ -33,6 +33,14 @@ def main():
     for k, v in gates.items():
         out["gate_" + k] = v
     out["onset_state"] = state
+    # the transport's inputs (r4: onset.rs:393-396, 404-440): a tick guard over the frames around the second fired onset,
+    # and the same stream before the latency calibration has completed
+    fired = np.nonzero(gates["flags"] & 16)[0]
+    sup = np.zeros(len(flux), np.uint8)
+    sup[max(0, fired[1] - 2):fired[1] + 3] = 1
+    masked, _, _ = oracle.onset_gates(mags, flux, energy, gf, suppress=sup)
+    uncal, _, _ = oracle.onset_gates(mags, flux, energy, gf, calibrated=False)
+    out["gate_suppress"], out["gate_flags_masked"], out["gate_flags_uncalibrated"] = sup, masked["flags"], uncal["flags"]
     # tuner geometry (stft.rs:169-174): 0.8 s of a chord
     y = _chord_signal(seconds=0.8, seed=78)
     tm = oracle.stft(y, 2048, 512, kind="mag")

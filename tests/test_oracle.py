@@ -378,6 +378,13 @@ def test_detector_restatements_vs_golden(oracle_mod):
     for k in ("flux", "energy_ema", "max_excess", "velocity"):
         assert np.allclose(gates[k], g["gate_" + k], rtol=2e-6, atol=1e-7), k
     assert int((g["gate_flags"] & 16 > 0).sum()) == 3
+    # the transport's inputs (tick guard mask, calibration flag): flags exactly
+    masked, _, _ = oracle_mod.onset_gates(mags, g["onset_flux"], g["onset_energy"], np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0),
+                                          suppress=g["gate_suppress"])
+    uncal, _, _ = oracle_mod.onset_gates(mags, g["onset_flux"], g["onset_energy"], np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0),
+                                         calibrated=False)
+    assert np.array_equal(masked["flags"], g["gate_flags_masked"]) and np.array_equal(uncal["flags"], g["gate_flags_uncalibrated"])
+    assert int((g["gate_flags_masked"] & 32 > 0).sum()) >= 1 and not np.any(g["gate_flags_uncalibrated"] & 16)
     tm = oracle_mod.stft(g["tuner_x"], 2048, 512, kind="mag")
     nb = tm.shape[1]
     eff, tstate, _ = oracle_mod.tuner_floor(tm, np.float32(10.0 ** (-60.0 / 20.0) * nb / 2.0))
