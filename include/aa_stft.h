@@ -153,7 +153,11 @@ int aa_stft_plan_destroy(aa_stft_plan *plan);
 int64_t aa_stft_num_frames(const aa_stft_plan *plan, int64_t n_samples);
 /* floats per output row for the plan's output kind. */
 int32_t aa_stft_out_cols(const aa_stft_plan *plan);
-/* Name of the kernel path the plan selected ("wave1024", "lds_stockham", "dft"). */
+/* Name of the FFT kernel family the plan selected: "wave1024" (one wave per frame; its log-mel / MFCC plans run
+ * stft_wave1024_mel_kernel), "wave1024x2" (opt-in, AA_W1024_X2=1 at plan creation: magnitude-type rows at hop 256 -
+ * falls back to "wave1024"'s kernel for a call whose buffers are not 16-byte aligned), "wave2048", "wave512",
+ * "wave256", "wave128" (several frames per wave), "wg_stockham" (one workgroup per frame: 4096 / 8192, and 1024 /
+ * 2048 at hops that are not multiples of 4), "lds_stockham" (other powers of two), "dft" (even non-powers of two). */
 const char *aa_stft_kernel_name(const aa_stft_plan *plan);
 
 /* Frames [frame_begin, frame_end) of the buffer `samples_dev[0 .. n_samples)`,
