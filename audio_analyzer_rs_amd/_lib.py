@@ -105,6 +105,7 @@ SIGNATURES = {
     "aa_stft_num_frames": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64]),
     "aa_stft_out_cols": (ctypes.c_int32, [ctypes.c_void_p]),
     "aa_stft_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "aa_stft_mel_path_name": (ctypes.c_char_p, [ctypes.c_void_p]),
     "aa_stft_execute_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                               ctypes.c_void_p]),

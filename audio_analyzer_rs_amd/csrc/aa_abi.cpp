@@ -135,44 +135,6 @@ void build_wave1024_table(const float *window, std::vector<float> *tab)
     }
 }
 
-// Per-lane constants of the two-frames-per-wave 1024 kernel (stft_wave1024x2_kernel), [kWave1024x2Rows][64];
-// l = lane & 31 (lane inside its frame), h = (lane >> 4) & 1, kappa = lane & 15, f = lane >> 5:
-//   rows  0..31  0.5 * w[2*(32 j + l) + c]                 (row 2j + c; pass A reads complex point 32 j + l)
-//   rows 32..61  W_512^(l k)  re,im   k = 1..15             (pass A twiddles)
-//   rows 62..77  W_32^(2 p + h)  re,im   p = 0..7           (radix-2 across the lane pair)
-//   rows 78..93  (-sin t, -cos t), t = 2 pi (l + 32 r)/1024, r = 0..7   (= -i W_1024^k, split)
-//   row  94      int bits: complex index of the lane's 16 values in the exchange image,
-//                f F + h P + 18 sigma(kappa)
-void build_wave1024x2_table(const float *window, std::vector<float> *tab)
-{
-    static const int sigma[16] = {2, 11, 6, 15, 0, 9, 4, 13, 8, 1, 12, 5, 10, 3, 14, 7};
-    tab->assign((size_t)aa::kWave1024x2Rows * 64, 0.0f);
-    float *T = tab->data();
-    for (int lane = 0; lane < 64; ++lane) {
-        const int l = lane & 31, h = (lane >> 4) & 1, kappa = lane & 15, f = lane >> 5;
-        for (int j = 0; j < 16; ++j)
-            for (int c = 0; c < 2; ++c)
-                T[(2 * j + c) * 64 + lane] = 0.5f * window[2 * (32 * j + l) + c];
-        for (int k = 1; k < 16; ++k) {
-            const double a = -2.0 * kPi * (double)(l * k) / 512.0;
-            T[(32 + 2 * (k - 1)) * 64 + lane] = (float)std::cos(a);
-            T[(33 + 2 * (k - 1)) * 64 + lane] = (float)std::sin(a);
-        }
-        for (int p = 0; p < 8; ++p) {
-            const double a = -2.0 * kPi * (double)(2 * p + h) / 32.0;
-            T[(62 + 2 * p) * 64 + lane] = (float)std::cos(a);
-            T[(63 + 2 * p) * 64 + lane] = (float)std::sin(a);
-        }
-        for (int r = 0; r < 8; ++r) {
-            const double th = 2.0 * kPi * (double)(l + 32 * r) / 1024.0;
-            T[(78 + 2 * r) * 64 + lane] = (float)(-std::sin(th));
-            T[(79 + 2 * r) * 64 + lane] = (float)(-std::cos(th));
-        }
-        const int32_t off = f * aa::kX2FrameStride + h * aa::kX2ParityStride + 18 * sigma[kappa];
-        std::memcpy(&T[94 * 64 + lane], &off, sizeof off);
-    }
-}
-
 constexpr int64_t kMfccSlab = 262144; // frames per log-mel slab of the fused MFCC path
 constexpr int64_t kMelSlab = 32768;  // frames per power-spectrogram slab (<= 134 MB: Infinity-Cache resident; 256 GEMM workgroups)
 
@@ -301,121 +263,6 @@ bool build_mel_sched(int sr, int n_fft, int n_mels, double fmin, double fmax, in
             q[2] = (float)(e * iu);
             q[3] = (float)(e * (c[i + 2] - (double)ks) * id);
             q[4] = (float)(e * id);
-        }
-    }
-    return true;
-}
-
-// kLogMelR (aa_internal.hpp): schedule over all 64 lanes + the per-lane table of resident
-// weights, taken from the dense float64 filterbank `w` [n_mels][nb] (so the values are those
-// of the GEMM path).  Fails when the schedule needs more than max_steps steps.
-bool build_mel_resident(const std::vector<double> &w, int nb, int n_mels, int max_steps,
-                        std::vector<float> *tab, aa::MelSched *sch)
-{
-    if (n_mels < 1 || n_mels > aa::kMelMaxMels)
-        return false;
-    std::vector<int> lo(n_mels, 0), len(n_mels, 0);
-    for (int m = 0; m < n_mels; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < nb; ++k)
-            if (w[(size_t)m * nb + k] != 0.0) {
-                if (first < 0)
-                    first = k;
-                last = k;
-            }
-        if (first >= 0) {
-            lo[m] = first;
-            len[m] = last - first + 1;
-        }
-    }
-    // a group's end costs about one 4-bin step here; fewer steps = fewer registers
-    if (!plan_mel_groups(len, n_mels, 64, nb, 4, sch))
-        return false;
-    int steps = 0;
-    for (int g = 0; g < sch->n_groups; ++g)
-        steps += sch->trips[g] / 4;
-    if (steps < 1 || steps > max_steps)
-        return false;
-    sch->n_steps = steps;
-    tab->assign(aa::kMelResidentTableDwords, 0.0f);
-    int s = 0;
-    for (int g = 0; g < sch->n_groups; ++g) {
-        const int pl = sch->part_log2[g], parts = 1 << pl, trips = sch->trips[g], base = sch->mel_base[g];
-        for (int t = 0; t < trips / 4; ++t, ++s) {
-            sch->step_info[s] = (t == trips / 4 - 1 ? 1 : 0) | (pl << 1) | (base << 4);
-            for (int lane = 0; lane < 64; ++lane) {
-                const int msub = lane >> pl, h = lane & (parts - 1), mel = base + msub;   // slices in adjacent lanes
-                if (mel >= n_mels)
-                    continue;   // weights 0, offset 0
-                const int ks = std::max(0, std::min(lo[mel], nb - parts * trips));
-                const int k0 = ks + h * trips + 4 * t;
-                for (int j = 0; j < 4; ++j)
-                    (*tab)[(size_t)(s * 5 + j) * 64 + lane] =
-                        k0 + j < nb ? (float)w[(size_t)mel * nb + k0 + j] : 0.0f;
-                const unsigned off = 4u * (unsigned)k0;
-                std::memcpy(&(*tab)[(size_t)(s * 5 + 4) * 64 + lane], &off, sizeof(unsigned));
-            }
-        }
-    }
-    return true;
-}
-
-// kLogMelR of the 2048 kernel (aa_internal.hpp: kMelStreamTableDwords): the schedule of
-// build_mel_resident with up to kMelStreamMaxSteps steps, the weights laid out for one
-// global_load_dwordx4 per (step, lane) and the byte offsets packed two per dword.
-bool build_mel_streamed(const std::vector<double> &w, int nb, int n_mels, std::vector<float> *tab,
-                        aa::MelSched *sch)
-{
-    if (n_mels < 1 || n_mels > aa::kMelMaxMels || 4 * nb > 65535)
-        return false;
-    std::vector<int> lo(n_mels, 0), len(n_mels, 0);
-    for (int m = 0; m < n_mels; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < nb; ++k)
-            if (w[(size_t)m * nb + k] != 0.0) {
-                if (first < 0)
-                    first = k;
-                last = k;
-            }
-        if (first >= 0) {
-            lo[m] = first;
-            len[m] = last - first + 1;
-        }
-    }
-    // a group's end costs one or two steps' worth of instructions (K-slice sums, the store)
-    int best_steps = 0;
-    for (int overhead : {4, 2}) {
-        aa::MelSched cand;
-        if (!plan_mel_groups(len, n_mels, 64, nb, overhead, &cand))
-            continue;
-        int steps = 0;
-        for (int g = 0; g < cand.n_groups; ++g)
-            steps += cand.trips[g] / 4;
-        if (steps >= 1 && (best_steps == 0 || steps < best_steps)) {
-            best_steps = steps;
-            *sch = cand;
-        }
-    }
-    if (best_steps < 1 || best_steps > aa::kMelStreamMaxSteps)
-        return false;
-    sch->n_steps = best_steps;
-    tab->assign(aa::kMelStreamTableDwords, 0.0f);
-    uint32_t *offs = reinterpret_cast<uint32_t *>(tab->data() + (size_t)aa::kMelStreamMaxSteps * 64 * 4);
-    int s = 0;
-    for (int g = 0; g < sch->n_groups; ++g) {
-        const int pl = sch->part_log2[g], parts = 1 << pl, trips = sch->trips[g], base = sch->mel_base[g];
-        for (int t = 0; t < trips / 4; ++t, ++s) {
-            sch->step_info[s] = (t == trips / 4 - 1 ? 1 : 0) | (pl << 1) | (base << 4);
-            for (int lane = 0; lane < 64; ++lane) {
-                const int msub = lane >> pl, h = lane & (parts - 1), mel = base + msub;   // slices in adjacent lanes
-                if (mel >= n_mels)
-                    continue;   // weights 0, offset 0
-                const int ks = std::max(0, std::min(lo[mel], nb - parts * trips));
-                const int k0 = ks + h * trips + 4 * t;
-                for (int j = 0; j < 4; ++j)
-                    (*tab)[((size_t)s * 64 + lane) * 4 + j] = k0 + j < nb ? (float)w[(size_t)mel * nb + k0 + j] : 0.0f;
-                offs[lane * 8 + (s >> 1)] |= (4u * (uint32_t)k0) << (16 * (s & 1));
-            }
         }
     }
     return true;
@@ -681,8 +528,8 @@ void build_wave_small_table(int n_fft, int hop, const float *window, std::vector
     // (flip, rot) per frame slot: exhaustive over the 4^FPW assignments (<= 65536), fewest passes,
     // ties to the plain map
     int flip[8] = {0}, rot[8] = {0}, best = small_read_passes(n_fft, hop, stages, FPW, LPF, flip, rot);
-    const char *plain = std::getenv("AA_SMALL_PLAIN_MAP");      // diagnostic: the unrelabelled map (PMC before / after)
-    if (best > 16 && !(plain && std::atoi(plain) != 0)) {
+    const bool plain = aa::experiment_knob("AA_SMALL_PLAIN_MAP", 0, 0, 1) != 0;   // experiment builds: the unrelabelled map (PMC before / after)
+    if (best > 16 && !plain) {
         int bf[8] = {0}, br[8] = {0};
         for (int code = 1; code < (1 << (2 * FPW)) && best > 16; ++code) {
             int f2[8], r2[8];
@@ -776,8 +623,6 @@ struct aa_stft_plan {
     bool wave128 = false;
     int frames_per_wg = 8;
     float *d_w1024_tab = nullptr;
-    float *d_w1024x2_tab = nullptr;    // stft_wave1024x2_kernel (n_fft 1024 at hop 256, magnitude-type rows)
-    bool wave1024x2 = false;
     // mel / MFCC post-ops (build-defined)
     int n_mels = 0, n_mels_pad = 0, n_mfcc = 0;
     float *d_melT = nullptr;       // [n_bins_pad x n_mels_pad]
@@ -790,10 +635,8 @@ struct aa_stft_plan {
     int64_t ws_logmel_rows = 0;
     // fused triangular mel reduction inside the wave kernels (n_fft 1024 / 2048)
     bool fused_mel = false;
-    bool mel_resident = false;     // kLogMelR: filter weights from a per-lane table (1024: resident in registers; 2048: streamed)
-    bool mfcc_fused = false;       // ... and the DCT-II behind it on the matrix cores (kMfccR)
     float *d_dct_lane = nullptr;   // its per-lane A-operand table [tile][8][64] float4
-    float *d_mel_par = nullptr;    // [kMelParTableDwords], [kMelResidentTableDwords] or [kMelStreamTableDwords]
+    float *d_mel_par = nullptr;    // [kMelParTableDwords]: the fallback gather (kLogMel)
     aa::MelSched mel_sched;
     // r4: the mel contraction on v_mfma_f32_4x4x1_16b_f32 (kLogMelM / kMfccM; n_fft 1024, 8 frames per chunk, n_mels % 4 == 0)
     bool mel_mfma = false, mfcc_mfma = false;
@@ -1148,8 +991,6 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
         if (cfg->n_fft == 1024 && cfg->hop % 4 == 0) {
             // frames per workgroup chunk: the tunable default, shrunk until the LDS need fits 64 KiB.
             int fpw = 8;
-            if (const char *s = std::getenv("AA_W1024_FRAMES_PER_WG"))
-                fpw = std::atoi(s) > 0 ? std::atoi(s) : fpw;
             while (fpw > 1 && aa::wave1024_lds_dwords(fpw, cfg->hop) > 16384)
                 --fpw;
             if (aa::wave1024_lds_dwords(fpw, cfg->hop) <= 16384) {
@@ -1161,87 +1002,52 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 p->frames_per_wg = fpw;
                 p->wave1024 = true;
             }
-            // hop 256 (the BASELINE geometry): AA_W1024_X2=1 at plan creation runs magnitude-type rows on the
-            // two-frames-per-wave kernel (stft_wave1024x2_kernel: 12.6 % fewer vector instructions, but three
-            // waves per SIMD - measured level with or 2-4 % behind the 8 x 8 x 8 kernel, DESIGN.md section 8;
-            // kept for A/B runs and parity-tested, not the default)
-            const char *x2 = std::getenv("AA_W1024_X2");
-            if (p->wave1024 && cfg->hop == 256 && x2 && std::atoi(x2) == 1) {
-                std::vector<float> tab;
-                build_wave1024x2_table(p->window_host.data(), &tab);
-                AA_HIP(hipMalloc(&p->d_w1024x2_tab, tab.size() * sizeof(float)));
-                AA_HIP(hipMemcpy(p->d_w1024x2_tab, tab.data(), tab.size() * sizeof(float),
-                                 hipMemcpyHostToDevice));
-                p->wave1024x2 = true;
-            }
         }
-        // Fused mel reduction in the wave kernels (the power rows never leave the CU); the slab +
-        // MFMA GEMM path stays for the generic kernels, unaligned input and AA_MEL_GEMM=1.
-        const char *force_gemm = std::getenv("AA_MEL_GEMM");
-        if (mel_out && !(force_gemm && std::atoi(force_gemm) != 0) &&
-            (p->wave2048 || (p->wave1024 && p->frames_per_wg == 8))) {
+        // Fused mel reduction in the wave kernels (the power rows never leave the CU); the slab + MFMA GEMM path stays for the
+        // generic kernels and unaligned input.  Which path a plan takes follows from its parameters alone (the parity tests
+        // reach every one of them that way: band counts that are no multiple of 4, other hops, n_mfcc > 64, n_fft 4096).
+        // Experiment builds (-DAA_EXPERIMENTS=1) can force the slower ones for A/B runs: AA_MEL_GEMM=1 the unfused path,
+        // AA_MEL_MFMA=0 the VALU gather instead of the contraction on the matrix cores, AA_MFCC_NO_FUSE=1 the DCT as a
+        // second launch.
+        auto selector = [](const char *name, int dflt) { return aa::experiment_knob(name, dflt, 0, 1); };
+        if (mel_out && selector("AA_MEL_GEMM", 0) == 0 && (p->wave2048 || (p->wave1024 && p->frames_per_wg == 8))) {
             const double fmax = cfg->fmax > 0.0f ? cfg->fmax : cfg->sample_rate / 2.0;
-            std::vector<float> par;
-            const int lanes = p->wave2048 ? 64 : 32;   // one frame per wave pass at 2048, two at 1024
-            const bool mel_lds_ok =
-                (p->wave2048 ? aa::wave2048_lds_dwords(p->frames_per_wg, cfg->hop, true)
-                             : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384;
-            const char *no_res = std::getenv("AA_MEL_NO_RESIDENT");
-            bool ok = false;
-            if (mel_lds_ok && !(no_res && std::atoi(no_res) != 0)) {
-                std::vector<double> w;
-                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
-                ok = p->mel_resident =
-                    p->wave1024 ? build_mel_resident(w, nb, cfg->n_mels, aa::kMelResidentSteps1024, &par, &p->mel_sched)
-                                : build_mel_streamed(w, nb, cfg->n_mels, &par, &p->mel_sched);
+            const bool use_mfma = selector("AA_MEL_MFMA", 1) != 0;
+            std::vector<double> w;
+            mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
+            // the contraction on v_mfma_f32_4x4x1_16b_f32: the 1024 kernel at 8 frames per chunk (log-mel, and MFCC with the
+            // DCT-II fused behind it: n_mfcc <= 64), the 2048 kernel at the tuner hop (BASELINE configs[2])
+            const bool fuse_dct = p->wave1024 && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
+                                  selector("AA_MFCC_NO_FUSE", 0) == 0;
+            std::vector<float> mt;
+            if (use_mfma && p->wave1024 && p->frames_per_wg == 8 && (cfg->output == AA_OUT_LOGMEL || fuse_dct) &&
+                aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, cfg->output == AA_OUT_MFCC ? 4 : 3) <= 16384)
+                p->mel_mfma = build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps, 8, aa::kMelMfmaRowB, false, &mt,
+                                             &p->mel_mfma_sched);
+            if (use_mfma && p->wave2048 && cfg->hop == 512 && p->frames_per_wg == 4 && cfg->output == AA_OUT_LOGMEL)
+                p->mel_mfma = build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps2048, 8, aa::kMelMfmaScratchDwords, true, &mt,
+                                             &p->mel_mfma_sched);
+            if (p->mel_mfma) {
+                AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
+                AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
             }
-            if (!ok && mel_lds_ok)
-                ok = build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes, &par,
-                                     &p->mel_sched);
-            if (ok) {
+            // the fallback for everything else the wave kernels take (other hops, band counts that are no multiple of 4,
+            // unaligned rows): the gather on the VALU with the weights rebuilt from the triangle edges
+            const int lanes = p->wave2048 ? 64 : 32;   // one frame per wave pass at 2048, two at 1024
+            std::vector<float> par;
+            if ((p->wave2048 ? aa::wave2048_lds_dwords(p->frames_per_wg, cfg->hop, true)
+                             : aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, true)) <= 16384 &&
+                build_mel_sched(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, lanes, &par, &p->mel_sched)) {
                 AA_HIP(hipMalloc(&p->d_mel_par, par.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_mel_par, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
                 p->fused_mel = true;
             }
-            // MFCC: the DCT-II fused behind the resident mel reduction (the log-mel rows never leave
-            // the CU).  The kernel folds each row about the middle of the mel axis (the DCT-II matrix
-            // is symmetric for even coefficients, antisymmetric for odd ones), so the A-operand table
-            // of v_mfma_f32_16x16x4_f32 holds half rows: tile = (parity, half) = 16 coefficients
-            // c = 2 (16 half + i) + parity, lane = (i = lane % 16, K-group kq = lane / 16), entry
-            // [tile][S][lane][t] = d[c][16 S + 4 kq + t], orthonormal DCT-II as above; zero outside
-            // n_mfcc / n_mels / 2.
-            const char *no_fuse = std::getenv("AA_MFCC_NO_FUSE");
-            const bool fuse_dct = p->wave1024 && cfg->output == AA_OUT_MFCC && cfg->n_mfcc <= 16 * aa::kMfccTiles &&
-                                  cfg->n_mels <= aa::kMelMaxMels && cfg->n_mels % 2 == 0 && !(no_fuse && std::atoi(no_fuse) != 0);
-            // r4: the contraction on the matrix cores (AA_MEL_MFMA=0 keeps the VALU gather for A/B runs)
-            const char *no_mfma = std::getenv("AA_MEL_MFMA");
-            if (p->wave1024 && p->frames_per_wg == 8 && !(no_mfma && std::atoi(no_mfma) == 0) &&
-                aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, cfg->output == AA_OUT_MFCC ? 4 : 3) <= 16384 &&
-                (cfg->output == AA_OUT_LOGMEL || fuse_dct)) {
-                std::vector<double> w;
-                std::vector<float> mt;
-                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
-                if (build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps, 8, aa::kMelMfmaRowB, false, &mt, &p->mel_mfma_sched)) {
-                    AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
-                    AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
-                    p->mel_mfma = true;
-                }
-            }
-            // the same on the 2048 kernel at the tuner hop (BASELINE configs[2]: stft_wave2048_mel_kernel)
-            if (p->wave2048 && cfg->hop == 512 && p->frames_per_wg == 4 && cfg->output == AA_OUT_LOGMEL &&
-                !(no_mfma && std::atoi(no_mfma) == 0)) {
-                std::vector<double> w;
-                std::vector<float> mt;
-                mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, fmax, &w);
-                if (build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps2048, 8, aa::kMelMfmaScratchDwords, true, &mt,
-                                   &p->mel_mfma_sched)) {
-                    AA_HIP(hipMalloc(&p->d_mel_mfma, mt.size() * sizeof(float)));
-                    AA_HIP(hipMemcpy(p->d_mel_mfma, mt.data(), mt.size() * sizeof(float), hipMemcpyHostToDevice));
-                    p->mel_mfma = true;
-                }
-            }
-            if (((ok && p->mel_resident && aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384) || p->mel_mfma) &&
-                fuse_dct) {
+            // MFCC: the DCT-II fused behind the contraction (the log-mel rows never leave the CU).  The kernel folds each
+            // row about the middle of the mel axis (the DCT-II matrix is symmetric for even coefficients, antisymmetric
+            // for odd ones), so the A-operand table of v_mfma_f32_16x16x4_f32 holds half rows: tile = (parity, half) = 16
+            // coefficients c = 2 (16 half + i) + parity, lane = (i = lane % 16, K-group kq = lane / 16), entry
+            // [tile][S][lane][t] = d[c][16 S + 4 kq + t], orthonormal DCT-II as above; zero outside n_mfcc / n_mels / 2.
+            if (p->mel_mfma && fuse_dct) {
                 std::vector<float> dl((size_t)aa::kMfccTableDwords, 0.0f);
                 for (int tile = 0; tile < aa::kMfccTiles; ++tile)
                     for (int S = 0; S < 4; ++S)
@@ -1259,8 +1065,7 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                             }
                 AA_HIP(hipMalloc(&p->d_dct_lane, dl.size() * sizeof(float)));
                 AA_HIP(hipMemcpy(p->d_dct_lane, dl.data(), dl.size() * sizeof(float), hipMemcpyHostToDevice));
-                p->mfcc_fused = ok && p->mel_resident && aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, 2) <= 16384;
-                p->mfcc_mfma = p->mel_mfma;
+                p->mfcc_mfma = true;
             }
         }
         return AA_OK;
@@ -1285,7 +1090,7 @@ int aa_stft_plan_destroy(aa_stft_plan *p)
             (void)hipStreamDestroy(st);
     if (p->pipe_event)
         (void)hipEventDestroy(p->pipe_event);
-    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_w1024x2_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_mel_mfma, p->d_dct_lane,
+    float *bufs[] = {p->d_window, p->d_w1024_tab, p->d_ws_in, p->d_ws_out, p->d_melT, p->d_dct, p->d_mel_par, p->d_mel_mfma, p->d_dct_lane,
                      p->d_ws_power, p->d_ws_logmel, reinterpret_cast<float *>(p->d_tile_k),
                      reinterpret_cast<float *>(p->d_dct_tile_k)};
     for (float *b : bufs)
@@ -1308,9 +1113,6 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
 {
     if (!p)
         return "";
-    if (p->wave1024x2 && (p->cfg.output == AA_OUT_MAG || p->cfg.output == AA_OUT_POWER ||
-                          p->cfg.output == AA_OUT_LOGPOWER))
-        return "wave1024x2";
     if (p->wave1024)
         return "wave1024";
     if (p->wave2048)
@@ -1324,6 +1126,18 @@ const char *aa_stft_kernel_name(const aa_stft_plan *p)
     if (p->tabs.pow2 && p->cfg.n_fft >= 1024)
         return "wg_stockham";
     return p->tabs.pow2 ? "lds_stockham" : "dft";
+}
+
+const char *aa_stft_mel_path_name(const aa_stft_plan *p)
+{
+    if (!p || (p->cfg.output != AA_OUT_LOGMEL && p->cfg.output != AA_OUT_MFCC))
+        return "";
+    const bool mfcc = p->cfg.output == AA_OUT_MFCC;
+    if (p->mel_mfma && (!mfcc || p->mfcc_mfma))
+        return mfcc ? "mfma+dct" : "mfma";
+    if (p->fused_mel)
+        return mfcc ? "gather+gemm" : "gather";
+    return "gemm";
 }
 
 static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
@@ -1357,7 +1171,7 @@ int aa_stft_execute_channels_device(aa_stft_plan *p, const float *samples_dev, i
     // slab paths of MFCC / mel) and the channels keep the 16-byte alignment of the first one
     const bool mel = p->cfg.output == AA_OUT_LOGMEL || p->cfg.output == AA_OUT_MFCC;
     const bool single_kernel = (p->wave1024 || p->wave2048) &&
-                               (!mel || (p->fused_mel && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_fused)) ||
+                               (!mel || (p->fused_mel && p->cfg.output == AA_OUT_LOGMEL) ||
                                 (p->mel_mfma && (p->cfg.output == AA_OUT_LOGMEL || p->mfcc_mfma)));
     const bool aligned = ((channel_stride | out_channel_stride) & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(samples_dev) & 15u) == 0 &&
@@ -1405,10 +1219,7 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
     // The FFT stage: frames [fb, fb+n) -> rows of `dst` in output kind `kind`.
     auto fft_stage = [&](int kind, int64_t fb, int64_t n, float *dst) -> int {
         const float *first = samples_dev + fb * (int64_t)p->cfg.hop;
-        if (p->wave1024x2 && (kind == aa::kMag || kind == aa::kPower || kind == aa::kLogPower) &&
-            ((reinterpret_cast<uintptr_t>(samples_dev) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
-            AA_HIP(aa::launch_wave1024x2(kind, samples_dev, dst, p->d_w1024x2_tab, fb, n, p->log_floor, st, chn));
-        } else if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
+        if (p->wave1024 && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
             AA_HIP(aa::launch_wave1024(kind, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
                                        p->frames_per_wg, p->log_floor, st, nullptr, nullptr, nullptr, 0, chn));
         } else if ((p->wave128 || p->wave256 || p->wave512) && (reinterpret_cast<uintptr_t>(first) & 15u) == 0) {
@@ -1451,11 +1262,11 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
     if (p->fused_mel && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
         auto mel_stage = [&](int64_t fb, int64_t n, float *dst) -> int {
             if (p->wave2048)
-                AA_HIP(aa::launch_wave2048(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
+                AA_HIP(aa::launch_wave2048(aa::kLogMel, samples_dev, dst,
                                            p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched, chn));
             else
-                AA_HIP(aa::launch_wave1024(p->mel_resident ? aa::kLogMelR : aa::kLogMel, samples_dev, dst,
+                AA_HIP(aa::launch_wave1024(aa::kLogMel, samples_dev, dst,
                                            p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched,
                                            nullptr, 0, chn));
@@ -1463,12 +1274,6 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
         };
         if (p->cfg.output == AA_OUT_LOGMEL)
             return mel_stage(frame_begin, nf, out_dev);
-        if (p->mfcc_fused) {
-            AA_HIP(aa::launch_wave1024(aa::kMfccR, samples_dev, out_dev, p->d_w1024_tab, frame_begin, nf,
-                                       p->cfg.hop, p->frames_per_wg, p->log_floor, st, p->d_mel_par,
-                                       &p->mel_sched, p->d_dct_lane, p->cfg.n_mfcc, chn));
-            return AA_OK;
-        }
         // log-mel rows are small (n_mels floats): one slab of up to 2^18 frames (<= 134 MB) so the
         // DCT GEMM runs as one large launch; the buffer grows on first use
         const int64_t slab = std::min<int64_t>(nf, kMfccSlab);

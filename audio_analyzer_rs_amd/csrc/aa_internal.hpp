@@ -29,14 +29,38 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
-// Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is
-// the fused triangular-filterbank reduction of the 1024 / 2048 wave kernels (rows of n_mels).
-// kMfccR: kLogMelR + the DCT-II fused behind it (1024 kernel only): the log-mel rows of 16 frames stay
-// in LDS and go through v_mfma_f32_16x16x4_f32 (see stft_wave1024_kernel).
-// kLogMelM / kMfccM (r4, 1024 kernel, 8 frames per chunk): the mel contraction band-blocked on
-// v_mfma_f32_4x4x1_16b_f32 (see "band-blocked mel contraction" below); kMfccM adds the fused DCT-II.
-enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelR = 5, kMfccR = 6,
-                     kLogMelM = 7, kMfccM = 8 };
+// Experiment knobs exist only in libraries built with -DAA_EXPERIMENTS=1 (tools/: A/B builds, path selectors of the
+// profiling scripts): the shipped library never reads the process environment - neither at plan creation nor on a
+// launch - except AA_RCCL_PATH, the deployment's location of librccl.so (aa_comm.cpp).  Values that do not parse
+// or fall outside [lo, hi] are ignored.
+#ifndef AA_EXPERIMENTS
+#define AA_EXPERIMENTS 0
+#endif
+inline int experiment_knob(const char *name, int dflt, int lo, int hi)
+{
+#if AA_EXPERIMENTS
+    if (const char *e = getenv(name)) {
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && *end == '\0' && v >= lo && v <= hi)
+            return (int)v;
+    }
+#else
+    (void)name;
+    (void)lo;
+    (void)hi;
+#endif
+    return dflt;
+}
+
+// Output kinds handled inside the FFT kernels' epilogue (AA_OUT_COMPLEX..LOGPOWER); kLogMel is the fused
+// triangular-filterbank reduction of the 1024 / 2048 wave kernels as a gather on the VALU with the weights rebuilt
+// from the triangle edges (the fallback: any band count, any hop, 4-byte-aligned rows).
+// kLogMelM / kMfccM (r4; 1024 kernel at 8 frames per chunk, 2048 kernel at hop 512; n_mels % 4 == 0): the mel
+// contraction band-blocked on v_mfma_f32_4x4x1_16b_f32 (see "band-blocked mel contraction" below); kMfccM adds the
+// DCT-II fused behind it on v_mfma_f32_16x16x4_f32 (the log-mel rows of 16 frames stay in LDS).
+// (Rounds 1-3 had kLogMelR / kMfccR = 5 / 6: the gather with resident / streamed weights; replaced by the M kinds.)
+enum OutKind : int { kComplex = 0, kMag = 1, kPower = 2, kLogPower = 3, kLogMel = 4, kLogMelM = 7, kMfccM = 8 };
 
 // ---- fused mel reduction (wave kernels, kLogMel) ------------------------------------
 // The filterbank is triangular: 98 % zeros, every bin feeds at most two filters, so the fused
@@ -55,12 +79,12 @@ constexpr int kMelParDwords = 6;
 constexpr int kMelParTableDwords = (kMelMaxMels + 1) * kMelParDwords + 2;   // 776, keeps 16-byte size
 constexpr int kMelStageDwords = 256;                // per wave: mel values of up to two frames
 constexpr int kMelLdsDwords = kMelParTableDwords + 4 * kMelStageDwords;
-// kMfccR: log-mel rows of two chunks (16 frames) in LDS, folded about the middle of the mel axis
-// (u = L[m] + L[M-1-m] in floats 0..63, v = L[m] - L[M-1-m] in floats 64..127; the DCT-II matrix is
-// symmetric / antisymmetric there), row stride 132 floats (the B-operand reads of the MFMA - 16 frames
-// x 4 K-groups, 16 bytes each - then spread over all 64 banks).  The DCT matrix comes as a per-lane
-// table [tile][4][64] float4: tile = (parity, half) = 16 coefficients c = 2 (16 half + i) + parity,
-// K ordered m = 16 S + 4 (lane / 16) + t: 4 tiles = up to 64 coefficients, n_mels even and <= 128.
+// kMfccM: log-mel rows of two chunks (16 frames) in LDS, row stride 132 floats (the B-operand reads of the DCT's MFMA -
+// 16 frames x 4 K-groups, 16 bytes each - then spread over all 64 banks); the fold about the middle of the mel axis
+// (u = L[m] + L[M-1-m] for the even coefficients, v = L[m] - L[M-1-m] for the odd ones: the DCT-II matrix is symmetric /
+// antisymmetric there) happens in the B operand.  The DCT matrix comes as a per-lane table [tile][4][64] float4:
+// tile = (parity, half) = 16 coefficients c = 2 (16 half + i) + parity, K ordered m = 16 S + 4 (lane / 16) + t: 4 tiles =
+// up to 64 coefficients, n_mels % 4 == 0 and <= 128.
 constexpr int kMfccRowStride = 132;
 constexpr int kMfccLdsDwords = 16 * kMfccRowStride;
 constexpr int kMfccTiles = 4;
@@ -71,25 +95,9 @@ struct MelSched {
     int trips[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};       // bins per K-slice (multiples of 4)
     int mel_base[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};
     int part_log2[kMelMaxGroups] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0, 1 or 2
-    // kLogMelR only: the groups flattened into n_steps 4-bin steps;
-    // step_info[s] = last step of its group (bit 0) | part_log2 << 1 | mel_base << 4
+    // kLogMelM / kMfccM: steps of the band-blocked contraction (the groups above are unused there)
     int n_steps = 0;
-    int step_info[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
-// kLogMelR (1024 kernel, weights resident in registers): the schedule must fit
-// kMelResidentSteps1024 steps of 4 bins (36 VGPRs); per-lane table [steps][5][64]: 4 weights + the
-// byte offset of the step's first bin in the power row (< 65536; the kernel packs two per register).
-constexpr int kMelResidentSteps1024 = 8;
-constexpr int kMelResidentTableDwords = kMelResidentSteps1024 * 5 * 64;
-// kLogMelR in the 2048 kernel: the same flattened schedule with the weights STREAMED from a per-lane
-// table every frame (the 2048 kernel has no registers to keep them: 168 of 170 at three waves per
-// SIMD) - one global_load_dwordx4 per 4-bin step replaces the nine VALU instructions that rebuild
-// the weights from the triangle edges (mel_reduce).  The table (<= 18 KB, read by every wave of the
-// chip once per frame) lives in the L1 / L2.  Layout: [kMelStreamMaxSteps][64 lanes][4] weights, then
-// [64 lanes][8] dwords of byte offsets into the power row, two 16-bit values per dword (step 2 i in
-// the low half of dword i).  The kernel is instantiated for 12, 14 and 16 steps.
-constexpr int kMelStreamMaxSteps = 16;
-constexpr int kMelStreamTableDwords = kMelStreamMaxSteps * 64 * 4 + 64 * 8;
 
 // ---- band-blocked mel contraction on the matrix cores (kLogMelM / kMfccM, r4) -------------------
 // After a workgroup barrier the power rows of all 8 frames of a chunk are visible in the four waves'
@@ -130,7 +138,7 @@ constexpr int kWave1024Threads = 256;              // 4 waves per workgroup
 constexpr int kWave1024ScratchDwords = 1056;       // per-wave E1 scratch / split strip / row staging
 // LDS dwords a workgroup needs for `frames_per_wg` frames: double-buffered unpadded staging
 // of (frames_per_wg-1)*hop + 1024 samples + the four per-wave scratch areas.
-// mel: 0 none, 1 fused mel reduction (kLogMel / kLogMelR), 2 fused MFCC (kMfccR), 3 kLogMelM, 4 kMfccM
+// mel: 0 none, 1 fused mel reduction (kLogMel), 3 kLogMelM, 4 kMfccM
 inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int mel = 0)
 {
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
@@ -138,7 +146,7 @@ inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int mel = 0)
     if (mel >= 3)
         return 2 * span + 4 * kMelMfmaScratchDwords + (mel == 4 ? kMfccLdsDwords : 0) + 4 +
                (span < kMelMfmaPartDwords ? kMelMfmaPartDwords : 0);       // (+ 4: the zero slot of the slice sums)
-    return 2 * span + 4 * kWave1024ScratchDwords + (mel == 2 ? kMfccLdsDwords : mel ? kMelLdsDwords : 0);
+    return 2 * span + 4 * kWave1024ScratchDwords + (mel ? kMelLdsDwords : 0);
 }
 inline size_t wave1024_lds_bytes(int frames_per_wg, int hop, int mel = 0)
 {
@@ -151,48 +159,23 @@ struct Channels {
     int n = 1;
     int64_t in_stride = 0, out_stride = 0;
 };
-// mel_par / sched are used by kLogMel only (null / nullptr otherwise).
-// dct_tab / n_mfcc: kMfccR only (kMfccTableDwords floats; n_mfcc <= 16 kMfccTiles).
+// mel_par / sched: kLogMel (the parameter table and the groups), kLogMelM / kMfccM (the kMelMfmaTableDwords table, n_mels
+// and n_steps); dct_tab / n_mfcc: kMfccM only (kMfccTableDwords floats; n_mfcc <= 16 kMfccTiles).
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
                            int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                            float log_floor, hipStream_t stream, const float *mel_par = nullptr,
                            const MelSched *sched = nullptr, const float *dct_tab = nullptr, int n_mfcc = 0,
                            const Channels *channels = nullptr);
 
-// kMfccR of launch_wave1024, defined in aa_kernels_mfcc.hip (arguments already validated by launch_wave1024)
-hipError_t launch_wave1024_mfcc(bool mfma_mel, const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
-                                int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
-                                const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch);
-
-// ---- two frames per wave, n_fft 1024 at hop 256 (the BASELINE geometry) -----------------------
-// stft_wave1024x2_kernel: the two adjacent frames of a wave sit side by side in its half-waves, 16
-// complex points per lane, 512 = 16 x 16 x 2: two radix-16 passes in registers, ONE exchange through
-// LDS and one cross-lane radix-2 (v_permlane16_swap) - no register transpose between passes.
-// Per-lane table [kWave1024x2Rows][64] (build_wave1024x2_table in aa_abi.cpp).
-// LDS: a ring of 11 blocks of 256 samples (the 8 + 3 blocks of a chunk; the next chunk's 8 new blocks
-// overwrite the 8 dead ones once every wave has its frames in registers), four per-wave scratch areas
-// (exchange image with its padding / split strips / row image) and the split-twiddle table [32][16].
-constexpr int kWave1024x2Rows = 95;
-constexpr int kX2RingBlocks = 11;
-constexpr int kX2ParityStride = 296;                  // complex: region of odd source lanes (8 mod 32: the other bank half)
-constexpr int kX2FrameStride = 592;                   // complex: image of the second frame
-constexpr int kX2ScratchDwords = 2 * (kX2FrameStride + kX2ParityStride + 16 * 18);   // 2352 floats = 9408 bytes
-constexpr int kX2RowImage = 2 * 2 * 264;               // floats: the row image of the pair behind the two split strips
-constexpr int kX2TwsStride = 20;                     // floats per lambda: 8 complex + 4 of padding (bank spread)
-constexpr int kX2TwsDwords = 32 * kX2TwsStride + 32;  // + W_32^(2 p + h), [2][16]
-inline size_t wave1024x2_lds_bytes()
-{
-    return sizeof(float) * (size_t)(kX2RingBlocks * 256 + 4 * kX2ScratchDwords + kX2TwsDwords);
-}
-// out_kind: kMag, kPower or kLogPower; hop 256, x and out 16-byte aligned.
-hipError_t launch_wave1024x2(int out_kind, const float *x, float *out, const float *table, int64_t frame_begin,
-                             int64_t n_frames, float log_floor, hipStream_t stream,
-                             const Channels *channels = nullptr);
+// kMfccM of launch_wave1024, defined in aa_kernels_mfcc.hip (arguments already validated by launch_wave1024)
+hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+                                float log_floor, hipStream_t stream, const float *mel_par, const MelSched &sch,
+                                const float *dct_tab, int n_mfcc, const Channels &ch);
 
 // ---- wave-per-frame 2048-point kernel (tuner geometry) ------------------------------
 constexpr int kWave2048Rows = 92;
-// behind the rows: the float4 tables the ring variant streams per frame - [8][64] window quadruples,
-// [4][64] pairs of combine twiddles, [4][64] pairs of split twiddles, [4][64] + [4][64] pairs of pass-A /
+// behind the rows, as float4 per lane: [8][64] window quadruples, [4][64] pairs of combine twiddles, [4][64] pairs
+// of split twiddles (stft_wave2048_mel_kernel streams these two per frame), [4][64] + [4][64] pairs of pass-A /
 // pass-B twiddles
 constexpr int kWave2048TableDwords = kWave2048Rows * 64 + 3 * 8 * 64 * 4;
 inline int64_t wave2048_lds_dwords(int frames_per_wg, int hop, bool mel = false)
@@ -204,13 +187,12 @@ inline size_t wave2048_lds_bytes(int frames_per_wg, int hop, bool mel = false)
 {
     return sizeof(float) * (size_t)wave2048_lds_dwords(frames_per_wg, hop, mel);
 }
-// kLogMelR: mel_par is the streamed table (kMelStreamTableDwords), sched->n_steps <= kMelStreamMaxSteps.
 // Ring variants (hop 512, 4 frames per chunk): `blocks` blocks of 256 floats + the four scratch areas
-// [+ the mel stage (kLogMelR: 2) or the parameter table and the stage (kLogMel: 1)].
+// [+ the parameter table and the stage (kLogMel: 1)].
 inline size_t wave2048_ring_lds_bytes(int blocks, int mel_kind)
 {
     return sizeof(float) * (size_t)(blocks * 256 + 4 * kWave1024ScratchDwords +
-                                    (mel_kind == 2 ? 4 * kMelStageDwords : mel_kind == 1 ? kMelLdsDwords : 0));
+                                    (mel_kind == 1 ? kMelLdsDwords : 0));
 }
 // stft_wave2048_mel_kernel: the ring, four scratch areas of the mel kinds' stride, a zero float4, [4][64] float4 of partial sums
 inline size_t wave2048_mel_lds_bytes()

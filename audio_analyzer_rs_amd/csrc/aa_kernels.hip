@@ -13,28 +13,6 @@
 namespace aa {
 namespace {
 
-// Clock probe for tools/ablate_w1024.hip (diagnostic builds only): shader cycles and
-// 100 MHz real-time ticks spent by each workgroup's wave 0.
-#ifdef AA_ABLATE
-__device__ unsigned long long aa_clk_dbg[4 * 8192];
-#define AA_CLK_BEGIN                                                                         \
-    unsigned long long clk_t0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime();
-#define AA_CLK_END                                                                           \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                             \
-        aa_clk_dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0_;                 \
-        aa_clk_dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0_;         \
-        aa_clk_dbg[4 * blockIdx.x + 2] = clk_r0_;                                            \
-        unsigned xcc_;                                                                       \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                  \
-        unsigned hwid_;                                                                      \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));                  \
-        aa_clk_dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc_ << 32) | hwid_;           \
-    }
-#else
-#define AA_CLK_BEGIN
-#define AA_CLK_END
-#endif
-
 // AA_SAFE_WAITS=1 (tools/check_counted_waits.sh only): every counted s_waitcnt becomes a full wait.  A
 // library built that way must produce the same bits as the shipped one; a counted wait that let a
 // load or an LDS-DMA piece slip would show as a difference.
@@ -83,37 +61,28 @@ __device__ __forceinline__ void wait_vmcnt_le()
 // wave waited for the samples of the NEXT chunk (and for all its row stores), which is exactly what the counted
 // chunk-top waits exist to avoid.  Safety is those waits' job: data moved by a piece is read only behind
 // wait_vmcnt_le<..>() + the workgroup barrier of the chunk that uses it.  lds_base must be wave-uniform.
-#ifndef AA_V_DMA_AUX
-#define AA_V_DMA_AUX 0     // cache policy bits of the LDS-DMA sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); builtin form only
-#endif
-#ifndef AA_V_DMA_ASM
-#define AA_V_DMA_ASM (AA_V_DMA_AUX == 0)     // 0: the builtin (compiler-tracked) form, for A/B runs
-#endif
 __device__ __forceinline__ void lds_dma_16(const float *src_lane, float *lds_base)
 {
-    if (AA_V_DMA_ASM) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(lds_base));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                     :
-                     : "v"(src_lane), "s"(base)
-                     : "memory");   // (m0 is written here and nowhere else in these kernels: the compiler has no use for it on gfx9)
-    } else {
+    if (AA_SAFE_WAITS) {
+        // the checking build (tools/check_counted_waits.sh): the compiler-tracked form, so that the compiler also puts
+        // its own full waits in front of the LDS accesses that may alias a DMA in flight
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
-                                         (__attribute__((address_space(3))) void *)lds_base, 16, 0, AA_V_DMA_AUX);
+                                         (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+        return;
     }
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(lds_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(src_lane), "s"(base)
+                 : "memory");   // no "m0" clobber: the compiler rejects it (m0 is a reserved register, -Winline-asm), and what it emits
+                                // itself that reads m0 (s_movrel, sendmsg, the LDS-DMA builtin) sets m0 right before the use - it holds no
+                                // value in m0 across statements for this asm to destroy
 }
-// Row stores: nontemporal (the rows are written once and not read by this kernel).  AA_V_STORE = 1
-// (experiments): plain stores.
-#ifndef AA_V_STORE
-#define AA_V_STORE 0
-#endif
+// Row stores: nontemporal (the rows are written once and not read by this kernel).
 template <typename T>
 __device__ __forceinline__ void row_store(T v, T *p)
 {
-    if (AA_V_STORE == 1)
-        *p = v;
-    else
-        __builtin_nontemporal_store(v, p);
+    __builtin_nontemporal_store(v, p);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -127,7 +96,7 @@ __device__ __forceinline__ float bin_from_power(float p, float log_floor)
 {
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR || OUT == kLogMelM || OUT == kMfccM)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelM || OUT == kMfccM)
         return p;
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
 }
@@ -138,7 +107,7 @@ __device__ __forceinline__ float bin_value(float re, float im, float log_floor)
     float p = re * re + im * im;
     if (OUT == kMag)
         return __builtin_amdgcn_sqrtf(p);
-    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR || OUT == kLogMelM || OUT == kMfccM)
+    if (OUT == kPower || OUT == kLogMel || OUT == kLogMelM || OUT == kMfccM)
         return p;
     // 10*log10(p) = (10/log2(10)) * log2(p)
     return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(p, log_floor));
@@ -262,30 +231,6 @@ __device__ __forceinline__ void pk_dft8(v2f (&v)[8])
     v[3] = pk_fma_mi(g, hp, d2); v[7] = pk_fma_pi(g, hp, d2);
 }
 
-// pk_dft8 of (v[j] * w[j]): the window multiply of stft.rs:296-299 folded into the first butterfly
-// stage - a_i = v_i w_i + v_{i+4} w_{i+4} is one multiply and one FMA, b_i one more FMA - 12 packed
-// instructions where the separate multiply + add / sub take 16.  (The products of the upper four
-// registers are not rounded on their own: the result is closer to the exact one by < 1 ulp.)
-__device__ __forceinline__ void pk_dft8_windowed(v2f (&v)[8], const v2f (&w)[8])
-{
-    const v2f hp = {0.70710678118654752440f, 0.70710678118654752440f};
-    const v2f t0 = v[0] * w[0], t1 = v[1] * w[1], t2 = v[2] * w[2], t3 = v[3] * w[3];
-    const v2f a0 = __builtin_elementwise_fma(v[4], w[4], t0), b0 = __builtin_elementwise_fma(-v[4], w[4], t0);
-    const v2f a1 = __builtin_elementwise_fma(v[5], w[5], t1), b1 = __builtin_elementwise_fma(-v[5], w[5], t1);
-    const v2f a2 = __builtin_elementwise_fma(v[6], w[6], t2), b2 = __builtin_elementwise_fma(-v[6], w[6], t2);
-    const v2f a3 = __builtin_elementwise_fma(v[7], w[7], t3), b3 = __builtin_elementwise_fma(-v[7], w[7], t3);
-    const v2f p = pk_add_mi(b1, b1);
-    const v2f q = pk_add_pi(b3, b3);
-    v2f c0 = a0 + a2, c2 = a0 - a2;
-    v2f c1 = a1 + a3, u = a1 - a3;
-    v2f d0 = pk_add_mi(b0, b2), d2 = pk_add_pi(b0, b2);
-    const v2f e = p - q, g = p + q;
-    v[0] = c0 + c1; v[4] = c0 - c1;
-    v[2] = pk_add_mi(c2, u); v[6] = pk_add_pi(c2, u);
-    v[1] = d0 + e * hp; v[5] = d0 - e * hp;
-    v[3] = pk_fma_mi(g, hp, d2); v[7] = pk_fma_pi(g, hp, d2);
-}
-
 // ---- cross-lane register transposes -----------------------------------------
 // "Swap bit p of the register index with bit q of the lane index" for an array of
 // 8 complex registers: for every pair (i, i|s), s = 1<<p, i&s == 0
@@ -366,11 +311,6 @@ __device__ __forceinline__ void exchange_high(v2f (&v)[8])
 }
 
 // ---- fused mel reduction (OUT == kLogMel) ---------------------------------------------
-// AA_MEL_ABL (diagnostic builds of tools/ablate_mel.sh only; 0 in the shipped library):
-// 1 no gather loops, 2 gather without its LDS reads, 4 no mel row stores, 8 no K-slice sums.
-#ifndef AA_MEL_ABL
-#define AA_MEL_ABL 0
-#endif
 // The Slaney filterbank is triangular (98 % zeros; a bin feeds at most two filters), so the fused
 // path is a gather on the VALU from the power rows the epilogue left in the wave's LDS scratch —
 // the rows never travel to HBM.  The wave's F frames get 64/F lanes each; within a frame, lane =
@@ -458,23 +398,17 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
             // prefetch may read <= 4 floats past the slice (inside the scratch, never used) and
             // everything is drained before the registers are reused
             v2f a0 = {0.0f, 0.0f}, a1 = a0, b0 = a0, b1 = a0;
-            if (!(AA_MEL_ABL & 3)) {
-                mel_lds_read2<0>(a0, addr);
-                mel_lds_read2<2>(a1, addr);
-            }
-            for (int i = 0; i < L && !(AA_MEL_ABL & 1); i += 8) {
-                if (!(AA_MEL_ABL & 2)) {
-                    mel_lds_read2<4>(b0, addr);
-                    mel_lds_read2<6>(b1, addr);
-                    mel_lds_wait<2>(a0, a1);
-                }
+            mel_lds_read2<0>(a0, addr);
+            mel_lds_read2<2>(a1, addr);
+            for (int i = 0; i < L; i += 8) {
+                mel_lds_read2<4>(b0, addr);
+                mel_lds_read2<6>(b1, addr);
+                mel_lds_wait<2>(a0, a1);
                 mel_step4(acc2, fi, a0, a1, ud0, dud);
                 if (i + 4 < L) {
-                    if (!(AA_MEL_ABL & 2)) {
-                        mel_lds_read2<8>(a0, addr);
-                        mel_lds_read2<10>(a1, addr);
-                        mel_lds_wait<2>(b0, b1);
-                    }
+                    mel_lds_read2<8>(a0, addr);
+                    mel_lds_read2<10>(a1, addr);
+                    mel_lds_wait<2>(b0, b1);
                     mel_step4(acc2, fi, b0, b1, ud0, dud);
                 }
                 addr += 32;
@@ -483,7 +417,7 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
             mel_lds_wait<0>(b0, b1);
             float acc = acc2.x + acc2.y;
             // sum the K-slices: h sits in the top bits of the frame's lane index
-            if (pl >= 1 && !(AA_MEL_ABL & 8)) {
+            if (pl >= 1) {
                 if (F == 1) {
                     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
                     acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -492,7 +426,7 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
                     acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
                 }
             }
-            if (pl >= 2 && !(AA_MEL_ABL & 8)) {
+            if (pl >= 2) {
                 if (F == 1) {
                     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
                     acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -503,251 +437,6 @@ __device__ __forceinline__ void mel_reduce(const float *rows, int nb, const floa
             const int mel = sch.mel_base[g] + msub;
             if (h == 0 && mel < kMelMaxMels)
                 stage[128 * f + mel] = acc;
-        }
-    }
-}
-// kLogMelR: the same reduction with the filter weights RESIDENT IN REGISTERS.  The weights of a
-// (lane, step) do not depend on the frame, and a persistent workgroup transforms ~100 frames:
-// computing them per frame (mel_reduce) costs more than the gather itself.  All 64 lanes are
-// (K-slice, mel-in-group) — at 1024 (F = 2) for BOTH frames of the wave (rows a and b, 2052 bytes
-// apart) — and the groups are flattened into <= NS steps of 4 bins; a lane keeps 4 weights (the
-// float64 filterbank rounded to f32 — the very values of the GEMM path) and the byte offset of
-// its 4 bins per step (two packed per register): 36 VGPRs at NS = 8 for the kernel's lifetime.
-// (Tried at 2048 with F = 1, NS = 14: 63 more VGPRs push that kernel to two waves per SIMD and
-// the FFT phase loses what the gather gains — 126 us either way — so 2048 keeps mel_reduce.)
-#ifndef AA_MEL_PK
-#define AA_MEL_PK 1        // resident gather: two bins per v_pk_fma_f32 (experiments: 0 = one FMA per bin)
-#endif
-template <int NS>
-struct MelResident {
-    v2f w[NS][2];
-    unsigned off2[(NS + 1) / 2];   // two 16-bit byte offsets per register
-    __device__ __forceinline__ unsigned off(int s) const { return (s & 1) ? off2[s >> 1] >> 16 : off2[s >> 1] & 0xffffu; }
-};
-template <int NS>
-__device__ __forceinline__ void mel_resident_load(MelResident<NS> &mr, const float *tab)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            mr.w[s][j] = v2f{tab[(s * 5 + 2 * j) * 64 + lane], tab[(s * 5 + 2 * j + 1) * 64 + lane]};
-    }
-#pragma unroll
-    for (int s = 0; s < NS; s += 2) {
-        const unsigned lo = __float_as_uint(tab[(s * 5 + 4) * 64 + lane]);
-        const unsigned hi = s + 1 < NS ? __float_as_uint(tab[((s + 1 < NS ? s + 1 : s) * 5 + 4) * 64 + lane]) : 0u;
-        mr.off2[s >> 1] = lo | (hi << 16);
-    }
-}
-template <int KEEP, int F>   // wait until at most KEEP newer LDS operations are outstanding
-__device__ __forceinline__ void mel_lds_wait_step(v2f (&c)[4])
-{
-    if (F == 2)
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(AA_SAFE_WAITS ? 0 : KEEP) : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : KEEP) : "memory");
-}
-template <int NS, int F>
-__device__ __forceinline__ void mel_reduce_resident(unsigned rows_addr, const MelResident<NS> &mr,
-                                                    const MelSched &sch, float *stage, int stride_b = 128)
-{
-    constexpr unsigned kRowB = 513 * 4;              // F == 2 (1024): row b = row a + 513 floats
-    constexpr int LPS = 2 * F;                       // ds_read2_b32 per step
-    constexpr int D = 12 / LPS;                      // steps in flight (<= 12 loads; lgkmcnt counts to 15)
-    const int lane = threadIdx.x & 63;
-    // opaque: keeps the NS (2 NS) per-step addresses from being hoisted out of the frame loop
-    // into as many long-lived VGPRs
-    asm volatile("" : "+v"(rows_addr));
-    // The compiler treats the result of a hand-issued load as available at once, so nothing it
-    // could turn into a register copy of a load in flight may sit between an issue and its wait:
-    // the code between them is straight-line except for the group ends (wave-uniform branches
-    // that touch only the accumulators).  All NS steps always run (unused steps carry zero
-    // weights); every step has its own registers {row a bins 0-1, 2-3 [, row b bins 0-1, 2-3]},
-    // the loads of D steps are in flight (the phase is bound by the LDS round trip, not by its
-    // FMAs); the sums of a group run through its steps as one FMA chain per frame.
-    v2f P[NS][4];
-    auto issue = [&](int s) {
-        const unsigned aa = rows_addr + mr.off(s);
-        P[s][0] = mel_lds_load2<0>(aa);
-        P[s][1] = mel_lds_load2<2>(aa);
-        if (F == 2) {
-            P[s][2] = mel_lds_load2<0>(aa + kRowB);
-            P[s][3] = mel_lds_load2<2>(aa + kRowB);
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < D && s < NS; ++s)
-        issue(s);
-    // (opaque lane index for the group ends: see mel_reduce)
-    int lp = lane;
-    asm volatile("" : "+v"(lp));
-    v2f acc_a = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f};   // even / odd bins of the chain (AA_MEL_PK)
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        v2f(&c)[4] = P[s];
-        constexpr int kMax = (D - 1) * LPS;
-        const int newer = (NS - 1 - s) * LPS;        // loads issued after this step's
-        if (newer >= kMax)
-            mel_lds_wait_step<kMax, F>(c);
-        else if (newer == 10)
-            mel_lds_wait_step<10, F>(c);
-        else if (newer == 8)
-            mel_lds_wait_step<8, F>(c);
-        else if (newer == 6)
-            mel_lds_wait_step<6, F>(c);
-        else if (newer == 4)
-            mel_lds_wait_step<4, F>(c);
-        else if (newer == 2)
-            mel_lds_wait_step<2, F>(c);
-        else
-            mel_lds_wait_step<0, F>(c);
-        if (AA_MEL_PK) {
-            acc_a = mr.w[s][1] * c[1] + (mr.w[s][0] * c[0] + acc_a);
-            if (F == 2)
-                acc_b = mr.w[s][1] * c[3] + (mr.w[s][0] * c[2] + acc_b);
-        } else {
-            acc_a.x = fmaf(mr.w[s][1].y, c[1].y, fmaf(mr.w[s][1].x, c[1].x, fmaf(mr.w[s][0].y, c[0].y, fmaf(mr.w[s][0].x, c[0].x, acc_a.x))));
-            if (F == 2)
-                acc_b.x = fmaf(mr.w[s][1].y, c[3].y, fmaf(mr.w[s][1].x, c[3].x, fmaf(mr.w[s][0].y, c[2].y, fmaf(mr.w[s][0].x, c[2].x, acc_b.x))));
-        }
-        // keep the step's FMAs here (its registers die, the next issue reuses them): otherwise
-        // all steps' loads are hoisted and their bins stay live
-        if (F == 2)
-            asm volatile("" : "+v"(acc_a), "+v"(acc_b));
-        else
-            asm volatile("" : "+v"(acc_a));
-        if (s + D < NS)
-            issue(s + D < NS ? s + D : s);
-        // Last step of a group (wave-uniform): the K-slices of a filter sit in adjacent lanes (lane =
-        // filter-in-group * slices + slice): sum them inside the quad, emit, start the next group.
-        // The ds_writes are newer than every load in flight: the counted waits only get more
-        // conservative.  (opaque: the predicates are SALU work per frame, not hoisted scalars)
-        int info = sch.step_info[s];
-        asm volatile("" : "+s"(info));
-        if (info & 1) {
-            const int pl = (info >> 1) & 7, base = info >> 4;
-            float sa = acc_a.x + acc_a.y, sb = acc_b.x + acc_b.y;
-            if (pl >= 1) {
-                sa += dpp_update<0xB1, 0xF>(sa, sa);             // quad_perm [1,0,3,2]
-                if (F == 2)
-                    sb += dpp_update<0xB1, 0xF>(sb, sb);
-            }
-            if (pl >= 2) {
-                sa += dpp_update<0x4E, 0xF>(sa, sa);             // quad_perm [2,3,0,1]
-                if (F == 2)
-                    sb += dpp_update<0x4E, 0xF>(sb, sb);
-            }
-            const int mel = base + (lp >> pl);
-            if ((lp & ((1 << pl) - 1)) == 0 && mel < kMelMaxMels) {
-                stage[mel] = sa;
-                if (F == 2)
-                    stage[stride_b + mel] = sb;
-            }
-            acc_a = v2f{0.0f, 0.0f};
-            acc_b = v2f{0.0f, 0.0f};
-        }
-    }
-}
-// kLogMelR in the 2048 kernel (F = 1): the schedule of mel_reduce_resident with the weights STREAMED
-// from the per-lane table (aa_internal.hpp: kMelStreamTableDwords) - the kernel has no registers to
-// keep them, and rebuilding them from the triangle edges (mel_reduce) costs nine VALU instructions
-// per 4-bin step against one global_load_dwordx4 here.  A step: the lane's four weights (global,
-// DW steps ahead), its four bins (two hand-issued ds_read2_b32, DL steps ahead), one v_pk_mul +
-// v_pk_fma + add.  The table is read once per frame by every wave of the chip and stays in the
-// L1 / L2.  All NS steps run (steps past the schedule have zero weights and read bins 0..3).
-template <int NS>
-__device__ __forceinline__ void mel_reduce_streamed(unsigned rows_addr, const float *tab, const MelSched &sch,
-                                                    float *stage)
-{
-    static_assert(NS <= kMelStreamMaxSteps && NS % 2 == 0, "streamed mel schedule");
-#ifndef AA_MEL_DL
-#define AA_MEL_DL 4
-#endif
-#ifndef AA_MEL_DW
-#define AA_MEL_DW 3
-#endif
-    constexpr int DL = AA_MEL_DL;                    // LDS steps in flight (two loads each; lgkmcnt counts to 15)
-    constexpr int DW = AA_MEL_DW;                    // weight loads in flight
-    const int ln = threadIdx.x & 63;
-    // the lane's byte offset into a table row: one 32-bit register next to the uniform base (saddr
-    // addressing).  Opaque, so that the per-step addresses are not hoisted out of the frame loop.
-    unsigned voff = 16u * (unsigned)ln;
-    asm volatile("" : "+v"(voff), "+v"(rows_addr));
-    // (opaque base as well: else every step's row address becomes a hoisted SGPR pair)
-    const char *tabb = reinterpret_cast<const char *>(tab);
-    unsigned sbase = 0;
-    asm volatile("" : "+s"(sbase));
-    auto weights = [&](int s) { return *reinterpret_cast<const v4f *>(tabb + (sbase + 1024u * s) + voff); };
-    const uint4 oa = *reinterpret_cast<const uint4 *>(tabb + 1024 * kMelStreamMaxSteps + 2 * voff);
-    const uint4 ob = NS > 8 ? *reinterpret_cast<const uint4 *>(tabb + 1024 * kMelStreamMaxSteps + 16 + 2 * voff)
-                            : uint4{0u, 0u, 0u, 0u};
-    const unsigned off2[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
-    v4f W[NS];
-#pragma unroll
-    for (int s = 0; s < DW && s < NS; ++s)
-        W[s] = weights(s);
-    v2f P[NS][2];
-    auto issue = [&](int s) {
-        const unsigned aa = rows_addr + ((s & 1) ? off2[s >> 1] >> 16 : off2[s >> 1] & 0xffffu);
-        P[s][0] = mel_lds_load2<0>(aa);
-        P[s][1] = mel_lds_load2<2>(aa);
-    };
-#pragma unroll
-    for (int s = 0; s < DL && s < NS; ++s)
-        issue(s);
-    // (opaque lane index for the group ends: their lane predicates are cheaper than the registers
-    // that would hold them across the FFT phase)
-    int lp = ln;
-    asm volatile("" : "+v"(lp));
-    v2f acc2 = {0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        v2f(&c)[2] = P[s];
-        constexpr int kMax = (DL - 1) * 2;
-        const int newer = (NS - 1 - s) * 2;          // LDS loads issued after this step's
-        if (newer >= kMax)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : kMax) : "memory");
-        else if (newer == 10)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 10) : "memory");
-        else if (newer == 8)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 8) : "memory");
-        else if (newer == 6)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 6) : "memory");
-        else if (newer == 4)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 4) : "memory");
-        else if (newer == 2)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(AA_SAFE_WAITS ? 0 : 2) : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1])::"memory");
-        const v2f w01 = {W[s].x, W[s].y}, w23 = {W[s].z, W[s].w};
-        acc2 = w01 * c[0] + acc2;
-        acc2 = w23 * c[1] + acc2;
-        // the step ends here: its registers die, the loads of the steps DL / DW ahead reuse them
-        asm volatile("" : "+v"(acc2), "+v"(voff));
-        if (s + DL < NS)
-            issue(s + DL < NS ? s + DL : s);
-        if (s + DW < NS)
-            W[s + DW < NS ? s + DW : s] = weights(s + DW);
-        // Last step of a group (wave-uniform): the K-slices of a filter sit in adjacent lanes (lane =
-        // filter-in-group * slices + slice): sum them inside the quad, emit, start the next group.
-        // The ds_write is newer than every load still in flight, so the counted waits above only
-        // get more conservative.  (opaque: the predicates are SALU work per frame, not hoisted
-        // scalars that would spill to VGPR lanes)
-        int info = sch.step_info[s];
-        asm volatile("" : "+s"(info));
-        if (info & 1) {
-            const int pl = (info >> 1) & 7, base = info >> 4;
-            float acc = acc2.x + acc2.y;
-            if (pl >= 1)
-                acc += dpp_update<0xB1, 0xF>(acc, acc);          // quad_perm [1,0,3,2]
-            if (pl >= 2)
-                acc += dpp_update<0x4E, 0xF>(acc, acc);          // quad_perm [2,3,0,1]
-            const int mel = base + (lp >> pl);
-            if ((lp & ((1 << pl) - 1)) == 0 && mel < kMelMaxMels)
-                stage[mel] = acc;
-            acc2 = v2f{0.0f, 0.0f};
         }
     }
 }
@@ -764,7 +453,7 @@ __device__ __forceinline__ void mel_store(const float *stage, const MelSched &sc
         float *row = ff == 0 ? row_a : row_b;
         const float v0 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(stage[128 * ff + lane], log_floor));
         const float v1 = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(stage[128 * ff + 64 + lane], log_floor));
-        if ((ff == 0 || valid_b) && !(AA_MEL_ABL & 4)) {
+        if (ff == 0 || valid_b) {
             if (lane < sch.n_mels)
                 row[lane] = v0;
             if (lane + 64 < sch.n_mels)
@@ -804,17 +493,8 @@ __device__ __forceinline__ void mel_mfma_load(MelMfma &mm, const float *tab_wave
 // dynamic chunk queue were measured too (tools/experiments/) and lost.
 // step is uniform across the workgroup; only the issue order changes, never a result.
 // Experiment switches of stft_wave1024_kernel (tools/ab_sustained.py builds one library per setting).
-#ifndef AA_V_WINFMA
-#define AA_V_WINFMA 0      // window multiply folded into the first butterfly stage of pass A
-#endif
 #ifndef AA_V_PAIR
 #define AA_V_PAIR 1        // a wave takes two ADJACENT frames of the chunk; their rows leave as one 4104-byte piece
-#endif
-#ifndef AA_V_TAIL
-#define AA_V_TAIL 0        // head / tail dwords of a row: one compare on per-lane bounds instead of nested branches
-#endif
-#ifndef AA_V_ILV
-#define AA_V_ILV 0         // interleaved chunk assignment (see stft_wave1024_kernel)
 #endif
 #ifndef AA_V_PKPOW
 #define AA_V_PKPOW 1       // |X[k]|^2 and |X[512-k]|^2 as one packed pair (one v_pk_mul + one v_pk_fma for both)
@@ -822,21 +502,9 @@ __device__ __forceinline__ void mel_mfma_load(MelMfma &mm, const float *tab_wave
 #ifndef AA_V_PKPOW2048
 #define AA_V_PKPOW2048 AA_V_PKPOW   // the same in stft_wave2048_kernel
 #endif
-#ifndef AA_V_SHARE
-#define AA_V_SHARE 0       // PAIR at hop 256: frame b takes six of its eight sample blocks from frame a's registers
-#endif
-#ifndef AA_V_HALO_COPY
-#define AA_V_HALO_COPY 0   // the 1024 - hop samples two consecutive chunks share: copied inside LDS instead of fetched by the next chunk's DMA again
-#endif
-#ifndef AA_V_WAIT_A
-#define AA_V_WAIT_A 0      // counted LDS wait: pass A of frame a starts when ITS eight reads are in, frame b's land under it
-#endif
 #ifndef AA_V_DMA_LATE
 #define AA_V_DMA_LATE 1    // magnitude-type and log-mel rows: the next chunk's LDS-DMA issued behind the frame reads of this chunk (r3: -0.8 %,
                            // 69.2 -> 68.65 us; log-mel -0.7 %); 2: every output kind
-#endif
-#ifndef AA_V_PIPE
-#define AA_V_PIPE 0        // PAIR: the frames of chunk c + 1 are read from LDS while the rows of chunk c are staged out
 #endif
 #ifndef AA_V_SPLIT
 #define AA_V_SPLIT 1       // uneven chunk runs: the remainder goes to the workgroups dispatched first
@@ -946,25 +614,23 @@ __device__ __forceinline__ void w1024_prio(int point, int prio_step)
 // A persistent workgroup (4 waves) owns a contiguous run of 8-frame chunks; chunk c+1 arrives by
 // LDS-DMA (global_load_lds_dwordx4) in the other half of a double buffer while chunk c is
 // transformed; each wave interleaves its two frames of the chunk.  All complex arithmetic is
-// packed f32 (pk_* helpers above).  ABL is the ablation mask of tools/ablate_w1024.hip (0 in the
-// shipped library): 1 no stores, 2 no E2, 4 no E1, 8 no DMA after the first chunk, 16 no split
-// strip, 32 no per-chunk wait/barrier, 64 vmcnt(0) at the chunk top, 256 rows to 32 L2 lines,
-// 512 E2 through LDS instead of registers (a correct variant: 80-83 us against 78-80), 1024 no
-// priority rotation.
-template <int OUT, int ABL = 0, bool WIDE = false, bool PIPE = false>
+// packed f32 (pk_* helpers above).  (r4: the ablation masks and the measured-and-rejected variants of
+// this kernel - software pipeline, halo copy inside LDS, interleaved chunk assignment, shared sample
+// blocks, split frame waits, E2 through LDS - live in tools/experiments/r04_wave1024_removed_variants.diff,
+// with their numbers; log-mel / MFCC rows run stft_wave1024_mel_kernel below, kLogMel here is the
+// fallback for filterbanks its plan does not hold.)
+template <int OUT, bool WIDE = false>
 __global__ __launch_bounds__(kWave1024Threads)
-__attribute__((amdgpu_waves_per_eu(OUT == kMfccR ? 3 : PIPE ? 4 : 1)))      // kMfccR: stay within 168 VGPRs (3 waves per SIMD); PIPE: within 128
 void stft_wave1024_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
-    float log_floor, const float *__restrict__ mel_par, MelSched sch, const float *__restrict__ dct_tab,
-    int n_mfcc, int n_streams, int64_t stream_in_stride, int64_t stream_out_stride)
+    float log_floor, const float *__restrict__ mel_par, MelSched sch, int n_streams, int64_t stream_in_stride,
+    int64_t stream_out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    AA_CLK_BEGIN
     int vgrid, vblock;
     {
         int64_t in_off, out_off;
@@ -978,21 +644,11 @@ void stft_wave1024_kernel(
     // cycles: the 64-bit multiplies of the first version cost ~450 cycles per frame).
     int c0, c1;
     chunk_run(n_chunks, c0, c1, vgrid, vblock);
-    // AA_V_ILV: interleaved chunks instead of one contiguous run per workgroup - at any time the
-    // resident workgroups work inside one window of gridDim.x chunks (8 MB of samples, 17 / 34 MB of
-    // rows), XCD x (= blockIdx % 8) on the x-th eighth of it so that neighbouring chunks share an L2:
-    // workgroup b takes chunks (b % 8) G/8 + b / 8 + i G.
-    const int cstep = AA_V_ILV ? (int)gridDim.x : 1;
-    if (AA_V_ILV) {
-        const int G = (int)gridDim.x, b = (int)blockIdx.x;
-        c0 = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
-        c1 = (int)n_chunks;
-    }
     const int max_span = (frames_per_wg - 1) * hop + 1024;
     v2f *scr = reinterpret_cast<v2f *>(smem + 2 * max_span + wave * kWave1024ScratchDwords);
     constexpr int NB = 513;
     constexpr int kPrioPattern = AA_W1024_PRIO >= 0 ? AA_W1024_PRIO : OUT == kComplex ? 3310 : 0;
-    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR || OUT == kMfccR;
+    constexpr bool MEL = OUT == kLogMel;
     constexpr bool PAIR = AA_V_PAIR && WIDE && !MEL && OUT != kComplex;
     // global stores a wave issues for its two rows of a full 8-frame chunk (every one is issued by
     // every wave: the lane masks never empty the wave) - the count the chunk-top wait leaves in flight
@@ -1000,13 +656,13 @@ void stft_wave1024_kernel(
                                        : !WIDE         ? 2 * 9                      // 9 dwords per row
                                        : PAIR          ? 5                          // 4 dwordx4 + 1 dwordx2 per row PAIR
                                                        : 2 * 3;                     // 2 dwordx4 + 1 dword per row
-    const int COLS = (OUT == kComplex) ? 2 * NB : OUT == kMfccR ? n_mfcc : MEL ? sch.n_mels : NB;
+    const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     const int64_t first_frame = (int64_t)c0 * frames_per_wg;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
     float *out_chunk = out + first_frame * COLS;                                // rows of chunk c
     int frames_left = (int)(n_frames - first_frame);                            // from chunk c on
-    const int src_stride = frames_per_wg * hop * cstep, out_stride = frames_per_wg * COLS * cstep;
-    const int frames_step = frames_per_wg * cstep;
+    const int src_stride = frames_per_wg * hop, out_stride = frames_per_wg * COLS;
+    const int frames_step = frames_per_wg;
     // fused mel: per-mel triangle parameters in LDS behind the scratch areas (visible after the
     // first chunk-top barrier)
     float *melpar = smem + 2 * max_span + 4 * kWave1024ScratchDwords;
@@ -1014,32 +670,17 @@ void stft_wave1024_kernel(
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
-    MelResident<kMelResidentSteps1024> mres;
-    if (OUT == kLogMelR || OUT == kMfccR)
-        mel_resident_load(mres, mel_par);
-    float *lm = melpar;                      // kMfccR: log-mel rows of two chunks, [16][kMfccRowStride]
 
     // LDS-DMA of `nfc` frames' samples starting at src into buffer `which`
     // (wave w moves the 1 KiB pieces w, w+4, ..)
-    // skip4 (AA_V_HALO_COPY): the first skip4 float4 of the span are NOT fetched - they are the 1024 - hop samples the next chunk
-    // shares with this one and are copied from this chunk's buffer inside LDS (halo_copy) instead of read from L2 again
-    auto stage = [&](const float *src, int nfc, int which, int skip4 = 0) {
+    auto stage = [&](const float *src, int nfc, int which) {
         const int span4 = ((nfc - 1) * hop + 1024) >> 2;
         float *dst = smem + which * max_span;
-        for (int qb = skip4 + wave * 64; qb < span4; qb += kWave1024Threads) {
+        for (int qb = wave * 64; qb < span4; qb += kWave1024Threads) {
             const int q = qb + lane;
             if (q < span4)
                 lds_dma_16(src + 4 * q, dst + 4 * qb);
         }
-    };
-    const int halo4 = AA_V_HALO_COPY && hop < 1024 ? (1024 - hop) >> 2 : 0;      // float4 shared by consecutive chunks
-    // behind the chunk-top barrier of chunk c (its samples have landed; every wave is done with the other buffer):
-    // buffer[other][0 .. halo) = buffer[cur][frames_per_wg hop ..), a quarter per wave
-    auto halo_copy = [&](int cur_buf) {
-        const v4f *from = reinterpret_cast<const v4f *>(smem + cur_buf * max_span + frames_per_wg * hop);
-        v4f *to = reinterpret_cast<v4f *>(smem + (cur_buf ^ 1) * max_span);
-        for (int q = tid; q < halo4; q += kWave1024Threads)
-            to[q] = from[q];
     };
 
     if (c0 < c1)
@@ -1066,60 +707,19 @@ void stft_wave1024_kernel(
     const unsigned smem_addr = lds_addr(smem);
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);                       // + 8 k1
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
-    const v4f *e2_rd = reinterpret_cast<const v4f *>(scr + 66 * (lane & 7) + 8 * (lane >> 3));
 
-#ifndef AA_V_MFCC_DEFER
-#define AA_V_MFCC_DEFER 1  // kMfccR: DCT results stored from the top of the next chunk
-#endif
-    v4f pend0 = {0.0f, 0.0f, 0.0f, 0.0f}, pend1 = pend0;   // kMfccR: accumulators of the last DCT block
-    float *pend_row = nullptr;
-    int pend_coef0 = 0;
-    bool pending = false;
-    auto flush_dct = [&]() {
-        if (OUT == kMfccR && AA_V_MFCC_DEFER && pending) {
-            const v4f d = pend0 + pend1;
-            if (pend_row) {
-                if (pend_coef0 + 0 < n_mfcc) pend_row[0] = d.x;
-                if (pend_coef0 + 2 < n_mfcc) pend_row[2] = d.y;
-                if (pend_coef0 + 4 < n_mfcc) pend_row[4] = d.z;
-                if (pend_coef0 + 6 < n_mfcc) pend_row[6] = d.w;
-            }
-            pending = false;
-        }
-    };
     int it = 0;
-    // AA_V_PIPE (PAIR, 8 frames per chunk): software pipeline over the chunks - the barrier that says "chunk c + 1
-    // has landed", the LDS-DMA of chunk c + 2 and the frame reads of chunk c + 1 sit at the END of chunk c's body,
-    // between the staging of its rows and their reads (pipe_hook below), so that the two LDS round trips overlap
-    // and the body starts with its frames already in registers; the classic chunk top runs for the first chunk only.
-    static_assert(!PIPE || (PAIR && !AA_V_ILV && !(ABL & 8)), "PIPE is a variant of the adjacent-frame magnitude path");
-    constexpr bool pipe = PIPE;                              // (the launcher instantiates it for 8 frames per chunk only)
     v2f va[8], vbv[8];
     bool dma_due = false;
-    if (pipe && c0 < c1) {
-        wait_vmcnt_le<0>();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
-        if (c0 + cstep < c1) {
-            const int nleft = frames_left - frames_step;
-            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, 1);
-        }
-        const unsigned fb = smem_addr + 4u * (unsigned)(2 * lane) + 4u * (unsigned)(2 * wave * hop);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)                          // (a wave without a frame reads too: no branch around the registers)
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(va[j]) : "v"(fb), "n"(512 * j) : "memory");
-        lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-    }
-    for (int c = c0; c < c1; c += cstep, ++it) {
+    for (int c = c0; c < c1; ++c, ++it) {
         const int cur = it & 1;
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
         const int prio_step = (int)(blockIdx.x >> 8) + 4 * it;   // dispatch round + quarter chunks
-        if (!pipe) {
         // The DMA loads of this chunk were issued before the previous chunk's row stores, and
         // vmcnt retires in order: leave exactly those stores in flight (a wave issued them for its
         // two frames of a full chunk) instead of waiting out their HBM latency every chunk.
-        if ((ABL & 64) || it == 0 || frames_per_wg != 8 || OUT == kMfccR)
-            wait_vmcnt_le<0>();              // (kMfccR: the few DCT stores of a chunk pair are long done)
+        if (it == 0 || frames_per_wg != 8)
+            wait_vmcnt_le<0>();
         else if (MEL && sch.n_mels > 64)
             wait_vmcnt_le<4>();                                  // 2 dword stores per mel row, 2 rows
         else if (MEL)
@@ -1128,93 +728,45 @@ void stft_wave1024_kernel(
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        if (!(ABL & 1024))
-            w1024_prio<kPrioPattern>(0, prio_step);
+        w1024_prio<kPrioPattern>(0, prio_step);
         // AA_V_DMA_LATE: the LDS-DMA of the next chunk is issued BEHIND this chunk's frame reads (its scalar address
         // loop then runs under their LDS round trip); the order of the vector-memory operations - DMA, then the
         // chunk's stores - is the same.  Waves without a frame (ragged last chunk only) issue it here.
         dma_due = false;
-        if (c + cstep < c1 && !(ABL & 8) && halo4 && cstep == 1)
-            halo_copy(cur);
-        if (c + cstep < c1 && !(ABL & 8)) {
+        if (c + 1 < c1) {
             if (AA_V_DMA_LATE && frames_per_wg == 8 && (PAIR ? 2 * wave : wave) < nf &&
-                (PAIR || OUT == kLogMel || OUT == kLogMelR || AA_V_DMA_LATE == 2))   // (MFCC +0.8 %, complex rows +0.4 % with it: left at the top)
+                (PAIR || OUT == kLogMel || AA_V_DMA_LATE == 2))   // (complex rows +0.4 % with it: left at the top)
                 dma_due = true;
             else {
                 const int nleft = frames_left - frames_step;
-                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1, cstep == 1 ? halo4 : 0);
+                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
             }
         }
-        } else if (!(ABL & 1024))
-            w1024_prio<kPrioPattern>(0, prio_step);
-        flush_dct();
         const int row0 = (c * frames_per_wg) & 31;           // row index mod 32 (alignment shift)
-        const unsigned buf_addr = smem_addr + 4u * (unsigned)(((ABL & 8) ? 0 : cur) * max_span + 2 * lane);
+        const unsigned buf_addr = smem_addr + 4u * (unsigned)(cur * max_span + 2 * lane);
 
         // ---- per-frame phases (lambdas so that two frames can be interleaved) ----------
-        auto read_frame_at = [&](unsigned base, int t, v2f (&v)[8]) {
-            const unsigned fr = base + 4u * (unsigned)(t * hop);
-            v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<512>(fr); v[2] = lds_read_b64<1024>(fr);
-            v[3] = lds_read_b64<1536>(fr); v[4] = lds_read_b64<2048>(fr); v[5] = lds_read_b64<2560>(fr);
-            v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
-        };
-        // pipe: in front of the row-image reads of the chunk's last epilogue (every wave of a full chunk passes here)
-        const bool has_next = c + cstep < c1;
-        auto pipe_hook = [&]() {
-            if (!has_next)
-                return;
-            if (it == 0)
-                wait_vmcnt_le<0>();                  // the DMA of chunk 1 was issued at the top: no stores behind it yet
-            else
-                wait_vmcnt_le<kRowStoresPerChunk>(); // .. DMA(c + 1) | stores(c - 1): leave those in flight
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();            // chunk c + 1 has landed; every wave is done with buffer `cur`
-            if (c + 2 * cstep < c1) {
-                const int nleft = frames_left - 2 * frames_step;
-                stage(src_chunk + 2 * src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur);
-            }
-            int lh = lane;
-            asm volatile("" : "+v"(lh));             // (opaque: a hoisted address would be spilled and reloaded behind the DMA)
-            const unsigned nb = smem_addr + 4u * (unsigned)((cur ^ 1) * max_span + 2 * lh);
-            read_frame_at(nb, 2 * wave, va);                 // (frame b is read at the top of the next body, under pass A of frame a)
-        };
         auto read_frame = [&](int t, v2f (&v)[8]) {
             const unsigned fr = buf_addr + 4u * (unsigned)(t * hop);
             v[0] = lds_read_b64<0>(fr); v[1] = lds_read_b64<512>(fr); v[2] = lds_read_b64<1024>(fr);
             v[3] = lds_read_b64<1536>(fr); v[4] = lds_read_b64<2048>(fr); v[5] = lds_read_b64<2560>(fr);
             v[6] = lds_read_b64<3072>(fr); v[7] = lds_read_b64<3584>(fr);
         };
-        auto pass_a = [&](v2f (&v)[8], bool windowed = false) {
-            if (AA_V_WINFMA && !windowed) {
-                pk_dft8_windowed(v, win);
-            } else {
-                if (!windowed) {
+        auto pass_a = [&](v2f (&v)[8]) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        v[j] = v[j] * win[j];
-                }
-                pk_dft8(v);
-            }
+            for (int j = 0; j < 8; ++j)
+                v[j] = v[j] * win[j];
+            pk_dft8(v);
             pk_twiddle7(v, twA);
         };
-        // PIPE: the exchange addresses are re-derived from an opaque copy of the lane index every chunk (four VALU
-        // operations) instead of holding two registers for the kernel's lifetime: the variant carries frame a's
-        // eight register pairs across the loop edge and must stay within 128 registers
-        int lx = lane;
-        if (PIPE)
-            asm volatile("" : "+v"(lx));
-        v2f *e1_wr_c = PIPE ? scr + 66 * (lx & 7) + (lx >> 3) : e1_wr;
-        const v4f *e1_rd_c = PIPE ? reinterpret_cast<const v4f *>(scr + 8 * (lx & 7) + 66 * (lx >> 3)) : e1_rd;
         auto exchange1 = [&](v2f (&v)[8]) {           // E1 through LDS
-            if (ABL & 4)
-                return;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
-                e1_wr_c[8 * kk] = v[kk];
+                e1_wr[8 * kk] = v[kk];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v4f qv = e1_rd_c[i];
+                v4f qv = e1_rd[i];
                 v[2 * i] = v2f{qv.x, qv.y};
                 v[2 * i + 1] = v2f{qv.z, qv.w};
             }
@@ -1223,48 +775,24 @@ void stft_wave1024_kernel(
         auto pass_bc = [&](v2f (&v)[8]) {
             pk_dft8(v);
             pk_twiddle7(v, twB);
-            if (ABL & 512) {
-                // E2 through LDS as well (variant timed by tools/ablate_w1024.hip): writer as E1,
-                // reader lane (k1 = L & 7, ka = L >> 3) takes 8 consecutive complex from 66 k1 + 8 ka
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    e1_wr[8 * kk] = v[kk];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v4f qv = e2_rd[i];
-                    v[2 * i] = v2f{qv.x, qv.y};
-                    v[2 * i + 1] = v2f{qv.z, qv.w};
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else if (!(ABL & 2)) {
-                hazard_fence(v);   // packed asm -> DPP / permlane read
-                exchange_high(v);
-            }
+            hazard_fence(v);   // packed asm -> DPP / permlane read
+            exchange_high(v);
             pk_dft8(v);
         };
         auto strip = [&](v2f (&v)[8], v2f (&prt)[4]) {   // partner half through the LDS strip
-            if (!(ABL & 16)) {
 #pragma unroll
-                for (int j = 4; j < 8; ++j)
-                    scr[lane + 64 * (j - 4)] = v[j];
-                if (lane == 0)
-                    scr[256] = v[0];
-                __builtin_amdgcn_wave_barrier();
+            for (int j = 4; j < 8; ++j)
+                scr[lane + 64 * (j - 4)] = v[j];
+            if (lane == 0)
+                scr[256] = v[0];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    prt[j] = scr[256 - (lane + 64 * j)];
-                __builtin_amdgcn_wave_barrier();
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    prt[j] = v[7 - j];
-            }
+            for (int j = 0; j < 4; ++j)
+                prt[j] = scr[256 - (lane + 64 * j)];
+            __builtin_amdgcn_wave_barrier();
         };
         auto epilogue = [&](v2f (&v)[8], v2f (&prt)[4], int t, bool valid, int slot) {
-            // ABL 256: all rows land in the first 32 rows of `out` (L2-resident): same store
-            // instructions, no HBM write stream
-            float *row = (ABL & 256) ? out + ((row0 + t) & 31) * COLS : out_chunk + t * COLS;
+            float *row = out_chunk + t * COLS;
             // stage by stage over the four pairs, so that no instruction reads the result of the one
             // just before it (a dependent packed pair back to back costs a wait state)
             v2f xk[4], xm[4], se[4], so[4], st[4];
@@ -1381,11 +909,7 @@ void stft_wave1024_kernel(
                     lrow[256] = m256;
                 return;
             }
-            if (ABL & 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    asm volatile("" ::"v"(mk[j]), "v"(mm[j]));
-            } else if (PAIR && frames_per_wg == 8) {
+            if (PAIR && frames_per_wg == 8) {
                 // The wave's two frames are ADJACENT (t = 2 wave, 2 wave + 1): their rows are one
                 // 4104-byte piece whose start is 0 or 2 floats past a 16-byte boundary (513 = 1 mod 4,
                 // the chunk's first row is a multiple of 8).  Both rows are staged (slot 0, slot 1),
@@ -1405,14 +929,10 @@ void stft_wave1024_kernel(
                     const float *lw = reinterpret_cast<const float *>(scr);
                     float *gw = row - NB - sh2;                          // window of row a
                     if (valid) {
-                        if (pipe)
-                            pipe_hook();
                         const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
                         const v4f q0 = lw4[0], q1 = lw4[64], q2 = lw4[128], q3 = lw4[192];
                         const int eo = sh2 ? 2 : 1024;
                         const v2f edge = *reinterpret_cast<const v2f *>(lw + eo);
-                        if (pipe && has_next)
-                            lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
                         __builtin_amdgcn_wave_barrier();
                         v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
                         row_store(q0, gw4);
@@ -1431,7 +951,7 @@ void stft_wave1024_kernel(
                         row_store(b0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
                         if (lane < 63)
                             row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                        if (PIPE ? (lane < 4 ? lane >= sh2 : (lane < 8 && lane - 4 <= sh2)) : (unsigned)(sh2 - tail_lo) <= tail_span)
+                        if ((unsigned)(sh2 - tail_lo) <= tail_span)
                             gw[hi] = hv;
                     }
                 }
@@ -1462,8 +982,7 @@ void stft_wave1024_kernel(
                     if (lane < 63)
                         row_store(b1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
                     // head floats sh..3 (lanes 0-3) and tail floats 512..512+sh (lanes 4-7)
-                    const bool ok = AA_V_TAIL ? (unsigned)(sh - tail_lo) <= tail_span
-                                              : lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
+                    const bool ok = lane < 4 ? (lane >= sh) : (lane < 8 && lane - 4 <= sh);
                     if (ok)
                         gw[hi] = hv;
                 }
@@ -1487,165 +1006,32 @@ void stft_wave1024_kernel(
             if (ta < nf) {
                 const bool vb = tb < nf;   // ragged last chunk: B computes on stale LDS, stores nothing
                 v2f pa[4], pb[4];
-                // AA_V_SHARE: adjacent frames at hop 256 overlap by six of the eight 128-float blocks a
-                // lane reads (block j of frame b = block j + 2 of frame a, same lane): frame b loads
-                // only its last two blocks and takes the others from frame a's registers
-                const bool share = AA_V_SHARE && PAIR && hop == 256;
-                if (pipe) {
-                    // frame a is in registers since the prologue / the previous chunk's pipe_hook; frame b's reads
-                    // fly under pass A of frame a
-                    read_frame(tb, vbv);
-                } else if (!share) {
-                    read_frame(ta, va);
-                    read_frame(tb, vbv);
-                    if (dma_due) {
-                        const int nleft = frames_left - frames_step;
-                        stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1, cstep == 1 ? halo4 : 0);
-                        dma_due = false;
-                    }
-                    if (AA_V_WAIT_A) {
-                        // frame a alone (LDS returns in order: at most frame b's eight reads still in flight);
-                        // frame b is waited for in front of its own pass A
-                        asm volatile("s_waitcnt lgkmcnt(8)"
-                                     : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7])
-                                     :: "memory");
-                    } else {
-                        lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-                        lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
-                    }
+                read_frame(ta, va);
+                read_frame(tb, vbv);
+                if (dma_due) {
+                    const int nleft = frames_left - frames_step;
+                    stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
+                    dma_due = false;
                 }
-                if (share)
-                    read_frame(ta, va);
-                if (share) {
-                    const unsigned frb = buf_addr + 4u * (unsigned)(tb * hop);
-                    vbv[6] = lds_read_b64<3072>(frb);
-                    vbv[7] = lds_read_b64<3584>(frb);
-                    lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vbv[6]), "+v"(vbv[7])::"memory");
-#pragma unroll
-                    for (int j = 0; j < 6; ++j)
-                        vbv[j] = va[j + 2] * win[j];
-                    vbv[6] = vbv[6] * win[6];
-                    vbv[7] = vbv[7] * win[7];
-                }
+                lds_wait_8(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7]);
+                lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
                 pass_a(va);
                 exchange1(va);
-                if (!(ABL & 1024))
-                    w1024_prio<kPrioPattern>(1, prio_step);
-                if (pipe || (AA_V_WAIT_A && !share))
-                    lds_wait_8(vbv[0], vbv[1], vbv[2], vbv[3], vbv[4], vbv[5], vbv[6], vbv[7]);
-                pass_a(vbv, share);
+                w1024_prio<kPrioPattern>(1, prio_step);
+                pass_a(vbv);
                 exchange1(vbv);
-                if (!(ABL & 1024))
-                    w1024_prio<kPrioPattern>(2, prio_step);
+                w1024_prio<kPrioPattern>(2, prio_step);
                 pass_bc(va);
                 strip(va, pa);
                 pass_bc(vbv);
                 strip(vbv, pb);
-                if (!(ABL & 1024))
-                    w1024_prio<kPrioPattern>(3, prio_step);
+                w1024_prio<kPrioPattern>(3, prio_step);
                 epilogue(va, pa, ta, true, 0);
                 epilogue(vbv, pb, tb, vb, 1);
                 if (OUT == kLogMel) {
                     __builtin_amdgcn_wave_barrier();
                     mel_reduce<2>(reinterpret_cast<const float *>(scr), NB, melpar, sch, melstage);
                     mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
-                } else if (OUT == kLogMelR) {
-                    __builtin_amdgcn_wave_barrier();
-                    mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, melstage);
-                    mel_store<2>(melstage, sch, log_floor, out_chunk + ta * COLS, out_chunk + tb * COLS, vb);
-                } else if (OUT == kMfccR) {
-                    // mel values of the two frames -> rows 8 (chunk parity) + t of the log-mel block,
-                    // 10 log10(max(., floor)) in place; columns past n_mels are zero (their DCT
-                    // weights are zero too, but 0 x garbage could be a NaN)
-                    __builtin_amdgcn_wave_barrier();
-                    float *rows = lm + (8 * (it & 1) + ta) * kMfccRowStride;
-                    // (rows 0..7 were read by the DCT at the top of this chunk: every wave is past it -
-                    // the barrier below the DCT phase)
-                    mel_reduce_resident<kMelResidentSteps1024, 2>(lds_addr(scr), mres, sch, rows, 4 * kMfccRowStride);
-                    __builtin_amdgcn_wave_barrier();
-                    // u[m] = L[m] + L[M-1-m], v[m] = L[m] - L[M-1-m] (m < M/2): the DCT-II matrix is
-                    // symmetric (even coefficients) / antisymmetric (odd) about the middle of the mel
-                    // axis, so the contraction is two of half the length
-                    const int half_m = sch.n_mels >> 1;
-                    int lf = lane;
-                    asm volatile("" : "+v"(lf));                        // (opaque: see the DCT phase)
-#pragma unroll
-                    for (int ff = 0; ff < 2; ++ff) {
-                        float *r = rows + ff * 4 * kMfccRowStride;
-                        const int mirror = lf < half_m ? sch.n_mels - 1 - lf : 0;
-                        const float la = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[lf], log_floor));
-                        const float lb = 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(r[mirror], log_floor));
-                        __builtin_amdgcn_wave_barrier();
-                        r[lf] = lf < half_m ? la + lb : 0.0f;
-                        r[64 + lf] = lf < half_m ? la - lb : 0.0f;
-                    }
-                }
-            }
-            if (OUT == kMfccR && ((it & 1) || c + cstep >= c1)) {
-                // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores.  Wave w owns a
-                // tile of 16 coefficients of one parity (w >> 1), c = 2 (16 (w & 1) + i) + parity:
-                // D[i][frame] = sum_{m < 64} Dm[c][m] u|v[frame][m] = 16 v_mfma_f32_16x16x4_f32 (an exact
-                // f32 fma chain per output).  A operand: lane = (i = lane % 16, K-group kq = lane / 16),
-                // 4 dwordx4 of the plan's table (L2 resident), fetched BEFORE the barrier so that their
-                // latency overlaps the wait for the other waves' rows; B operand: lane = (kq, frame
-                // j = lane % 16), 4 ds_read_b128 of row j.  K order m = 16 S + 4 kq + t for step 4 S + t
-                // (any order will do as long as A and B agree).  No barrier behind the phase: the rows
-                // are rewritten at the END of the next chunk, which starts with a barrier of its own.
-                // (Measured alternatives: the phase behind the NEXT chunk-top barrier, with the A operand
-                // fetched before that barrier or carried over from the end of this chunk, costs 20+
-                // VGPR spills - the top of the chunk loop is where the register allocator keeps most
-                // alive - and runs at 128 us against 99.)
-                // (the lane index goes through an opaque copy: otherwise the per-lane addresses below are
-                // loop invariant, get hoisted out of the chunk loop and stay live through the FFT phases)
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
-                const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + ln;
-                const v4f a0 = at[0], a1 = at[64], a2 = at[128], a3 = at[192];
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_s_barrier();
-                const v4f *bt = reinterpret_cast<const v4f *>(lm + (ln & 15) * kMfccRowStride + 64 * (wave >> 1) +
-                                                            4 * (ln >> 4));
-                const v4f b0 = bt[0], b1 = bt[4], b2 = bt[8], b3 = bt[12];
-                v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, b3.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, b3.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b2.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, b3.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b2.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, b3.w, acc1, 0, 0, 0);
-                // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
-                const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
-                const int have = (it & 1) ? 8 + nf : nf;               // valid rows (a lone last chunk: rows 0..7)
-                // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's
-                float *orow = ((it & 1) ? (j < 8 ? out_chunk - out_stride + j * COLS : out_chunk + (j - 8) * COLS)
-                                        : out_chunk + j * COLS) + coef0;
-                if (AA_V_MFCC_DEFER) {
-                    // the 16 MFMAs take ~500 cycles to drain: their results are stored from the top of
-                    // the next chunk (or behind the loop), not waited for here
-                    pend0 = acc0;
-                    pend1 = acc1;
-                    pend_row = j < have ? orow : nullptr;
-                    pend_coef0 = coef0;
-                    pending = true;
-                } else {
-                    const v4f d = acc0 + acc1;
-                    if (j < have) {
-                        if (coef0 + 0 < n_mfcc) orow[0] = d.x;
-                        if (coef0 + 2 < n_mfcc) orow[2] = d.y;
-                        if (coef0 + 4 < n_mfcc) orow[4] = d.z;
-                        if (coef0 + 6 < n_mfcc) orow[6] = d.w;
-                    }
                 }
             }
         } else {
@@ -1669,8 +1055,6 @@ void stft_wave1024_kernel(
         out_chunk += out_stride;
         frames_left -= frames_step;
     }
-    flush_dct();
-    AA_CLK_END
 }
 
 // ------------------------------- n_fft = 1024, log-mel / MFCC rows (kLogMelM / kMfccM, r4) --
@@ -2067,493 +1451,6 @@ void stft_wave1024_mel_kernel(
     flush_dct();
 }
 
-// ------------------------------ two frames per wave, n_fft = 1024 at hop 256 (BASELINE geometry) --
-// stft_wave1024x2_kernel: the two ADJACENT frames a wave owns (t = 2 wave, 2 wave + 1 of an 8-frame chunk)
-// sit side by side in its half-waves: frame f in lanes 32 f .. 32 f + 31, SIXTEEN complex points per
-// lane, 512 = 16 x 16 x 2:
-//   pass A  radix-16 over j in registers (lane l reads z[32 j + l], j = 0..15), x W_512^(l k1)
-//   E1      registers <-> lanes through the wave's LDS scratch: lane (f, l) stores T[k1] at complex
-//           f F + (l & 1) P + off[k1] + (l >> 1), lane (f, h, kappa) = 32 f + 16 h + kappa loads the 16
-//           consecutive complex T[kappa][2 i + h] from f F + h P + off[kappa] (8 x ds_read_b128).
-//           off[] = 18 sigma(k1) and P = 296 make both sides bank-conflict free (simulated on the lane
-//           groups of the LDS: tools/wave_sim_1024x2.py)
-//   pass B  radix-16 over i in registers: E_q in the h = 0 lane, O_q in the h = 1 lane, q = 0..15
-//   radix-2 across the lane pair (kappa, 0 | 1): v_permlane16_swap(r[2p], r[2p+1]) hands lane h the pair
-//           (E_q, O_q) for q = 2 p + h; Z[kappa + 16 q] = E_q + W_32^q O_q, Z[.. + 256] = E_q - W_32^q O_q
-//           -> lane lambda = kappa + 16 h holds Z[lambda + 32 r] in register r = 0..15 (natural order)
-//   split   X[k], X[512-k] from Z[k], conj(Z[512-k]), k = lambda + 32 r, r < 8; the partners
-//           (registers 8..15) cross a strip in the scratch; -i W_1024^k from a table in LDS
-//   store   the two rows (one 4104-byte piece, 0 or 2 floats past a 16-byte boundary) staged in the
-//           scratch, 4 nontemporal dwordx4 + 1 dwordx2 per wave as in stft_wave1024_kernel
-// Against stft_wave1024_kernel (8 x 8 x 8, one frame per wave at a time, two interleaved): the 8 x 8
-// register transpose between passes B and C (16 DPP moves + 16 permlane swaps per frame, 148 of that
-// kernel's ~920 VALU cycles per frame) becomes 8 permlane swaps per frame, two twiddle layers of 7/8
-// become 15/16 + 1/2, and the butterfly count stays (two radix-16 = 82 packed instructions per 16
-// points, three radix-8 = 84 per 8 points over... the same 9 stages).  Price: 16 data registers per
-// lane and twice the per-lane constants (window 32, pass-A twiddles 30, W_32 16) -> 3 waves per
-// SIMD, 9.2 KB of exchange scratch per wave -> 3 workgroups per CU.
-// Staging: a ring of 11 blocks of 256 samples (block b of the workgroup's run in slot b mod 11).  A
-// chunk's frames read blocks 8 i .. 8 i + 10; once every wave holds its frames in registers (second
-// barrier) blocks 8 i .. 8 i + 7 are dead and the 8 new blocks of chunk i + 1 land on them by LDS-DMA
-// while chunk i is transformed.
-constexpr int kX2E1Sigma[16] = {2, 11, 6, 15, 0, 9, 4, 13, 8, 1, 12, 5, 10, 3, 14, 7};
-// -i (a - b)
-__device__ __forceinline__ v2f pk_sub_mi(v2f a, v2f b)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a * w for a wave-uniform constant w held in an SGPR pair (VOP3P reads one scalar operand)
-__device__ __forceinline__ v2f pk_cmul_lo_s(v2f a, v2f w)
-{
-    v2f t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
-    return t;
-}
-__device__ __forceinline__ v2f pk_cmul_hi_s(v2f a, v2f w, v2f t)
-{
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
-    return r;
-}
-// 16-point DFT over the register index, natural order in and out: one radix-2 DIF stage, the odd half
-// times W_16^i (i = 4: the rotation by -i rides in the subtraction), two 8-point DFTs.
-__device__ __forceinline__ void pk_dft16(v2f (&v)[16])
-{
-    const v2f w1 = {0.92387953251128673848f, -0.38268343236508978178f};   // W_16^1
-    const v2f w2 = {0.70710678118654752440f, -0.70710678118654752440f};   // W_16^2
-    const v2f w3 = {0.38268343236508978178f, -0.92387953251128673848f};   // W_16^3
-    const v2f w5 = {-0.38268343236508978178f, -0.92387953251128673848f};  // W_16^5
-    const v2f w6 = {-0.70710678118654752440f, -0.70710678118654752440f};  // W_16^6
-    const v2f w7 = {-0.92387953251128673848f, -0.38268343236508978178f};  // W_16^7
-    v2f a[8], b[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        a[i] = v[i] + v[i + 8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        b[i] = i == 4 ? pk_sub_mi(v[4], v[12]) : v[i] - v[i + 8];
-    // (every multiply ahead of every dependent FMA: a dependent packed pair back to back costs a wait state)
-    const v2f t1 = pk_cmul_lo_s(b[1], w1), t2 = pk_cmul_lo_s(b[2], w2), t3 = pk_cmul_lo_s(b[3], w3);
-    const v2f t5 = pk_cmul_lo_s(b[5], w5), t6 = pk_cmul_lo_s(b[6], w6), t7 = pk_cmul_lo_s(b[7], w7);
-    pk_dft8(a);
-    b[1] = pk_cmul_hi_s(b[1], w1, t1); b[2] = pk_cmul_hi_s(b[2], w2, t2); b[3] = pk_cmul_hi_s(b[3], w3, t3);
-    b[5] = pk_cmul_hi_s(b[5], w5, t5); b[6] = pk_cmul_hi_s(b[6], w6, t6); b[7] = pk_cmul_hi_s(b[7], w7, t7);
-    pk_dft8(b);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        v[2 * q] = a[q];
-        v[2 * q + 1] = b[q];
-    }
-}
-__device__ __forceinline__ void lds_wait_16(v2f (&v)[16])
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                 :
-                 : "memory");
-}
-// packed asm -> permlane read: two wait states, every producer before, every consumer behind (hazard_fence)
-__device__ __forceinline__ void hazard_fence16(v2f (&v)[16])
-{
-    asm volatile("s_nop 1"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                   "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-}
-#ifndef AA_X2_PRIO
-#define AA_X2_PRIO 11         // wave priority of the two-frame kernel (x2_prio below): 11 measured best, 0 none
-#endif
-#ifndef AA_X2_E1ILV
-#define AA_X2_E1ILV 0         // 1: exchange writes interleaved with the twiddle FMAs (groups of four)
-#endif
-#ifndef AA_X2_E1ORD
-#define AA_X2_E1ORD 0         // 1: exchange reads in the order pass B's first butterflies consume them
-#endif
-#ifndef AA_X2_ABL
-#define AA_X2_ABL 0           // timing-only ablations (wrong rows): 1 no second barrier and no DMA after the first chunk, 2 no row stores
-#endif
-
-// Wave priority of the two-frame kernel at point pt of the chunk body (0 top / pass A, 1 in front of the exchange
-// writes, 2 behind the exchange reads / pass B, 3 in front of the strip writes, 4 behind the strip reads / split,
-// 5 in front of the row-image reads), r = dispatch round of the workgroup + chunk count.  AA_X2_PRIO:
-//   0 none | 1 three levels at points 0, 2, 4 | 4 three levels at 0, 1, 3 (changes in front of the LDS phases)
-//   5 three levels at all six points | 6 static 2 - round | 7 as 1, rotating the other way | 8 as 1 with levels 3..1
-//   9 as 1, the assignment moving on by one every chunk
-__device__ __forceinline__ void x2_prio(int pt, int r)
-{
-    int step = -1;
-    if (AA_X2_PRIO == 1 || AA_X2_PRIO == 7 || AA_X2_PRIO == 8 || AA_X2_PRIO == 9)
-        step = pt == 0 ? 0 : pt == 2 ? 1 : pt == 4 ? 2 : -1;
-    if (AA_X2_PRIO == 4)
-        step = pt == 0 ? 0 : pt == 1 ? 1 : pt == 3 ? 2 : -1;
-    if (AA_X2_PRIO == 5)
-        step = pt;
-    if (AA_X2_PRIO == 6)
-        step = pt == 0 ? 0 : -1;
-    if (AA_X2_PRIO == 11 || AA_X2_PRIO == 12) {          // by phase only, the same in every workgroup: later phases first (11) / last (12)
-        const int lvl = pt == 0 ? 0 : pt == 2 ? 1 : pt == 4 ? 2 : pt == 5 ? 3 : -1;
-        if (lvl == 0) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 0 : 3);
-        if (lvl == 1) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 1 : 2);
-        if (lvl == 2) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 2 : 1);
-        if (lvl == 3) __builtin_amdgcn_s_setprio(AA_X2_PRIO == 11 ? 3 : 0);
-        return;
-    }
-    if (AA_X2_PRIO == 13) {                               // as 1, and level 3 from the front of each LDS burst to the next rotation point
-        if (pt == 1 || pt == 3 || pt == 5) {
-            __builtin_amdgcn_s_setprio(3);
-            return;
-        }
-        step = pt == 0 ? 0 : pt == 2 ? 1 : 2;
-    }
-    if (step < 0)
-        return;
-    const int k = AA_X2_PRIO == 6 ? r % 3 : AA_X2_PRIO == 7 ? (2 * r + 3 - step % 3) % 3 : (r + step) % 3;
-    const int base = AA_X2_PRIO == 8 ? 1 : 0;
-    if (k == 0)
-        __builtin_amdgcn_s_setprio(2 + base);
-    else if (k == 1)
-        __builtin_amdgcn_s_setprio(1 + base);
-    else
-        __builtin_amdgcn_s_setprio(0 + base);
-}
-
-template <int OUT>
-__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void stft_wave1024x2_kernel(
-    const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
-    int64_t frame_begin, int64_t n_frames, int64_t n_chunks, float log_floor,
-    int n_streams, int64_t stream_in_stride, int64_t stream_out_stride)
-{
-    static_assert(OUT == kMag || OUT == kPower || OUT == kLogPower, "magnitude-type rows only");
-    // Three SEPARATE LDS objects, not one dynamic array: the compiler tracks an LDS-DMA in flight per LDS
-    // object it can tell apart (alias scopes of distinct __shared__ variables) and puts an s_waitcnt vmcnt(0)
-    // in front of the first DS access that may alias it - with a single extern array that is the first
-    // exchange write of every chunk, i.e. every wave would wait there for the samples of the NEXT chunk.
-    __shared__ __attribute__((aligned(16))) float ring[kX2RingBlocks * 256];
-    __shared__ __attribute__((aligned(16))) float scratch[4 * kX2ScratchDwords];
-    __shared__ __attribute__((aligned(16))) float tws_tab[kX2TwsDwords];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = lane >> 5, l = lane & 31;                   // frame of the pair, lane inside the frame
-    int vgrid, vblock;
-    {
-        int64_t in_off, out_off;
-        stream_of_block(n_streams, stream_in_stride, stream_out_stride, in_off, out_off, vgrid, vblock);
-        x += in_off;
-        out += out_off;
-    }
-    int c0, c1;
-    chunk_run(n_chunks, c0, c1, vgrid, vblock);
-    constexpr int NB = 513, HOP = 256, FPC = 8;               // bins per row, hop, frames per chunk
-    constexpr int kRowStores = 5;                             // 4 dwordx4 + 1 dwordx2 per wave and full chunk
-    v2f *scr = reinterpret_cast<v2f *>(scratch + wave * kX2ScratchDwords);
-
-    const int64_t first_frame = (int64_t)c0 * FPC;
-    const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)HOP;   // first sample of chunk c
-    float *out_chunk = out + first_frame * NB;
-    int frames_left = (int)(n_frames - first_frame);
-
-    // LDS-DMA of `nblk` consecutive 256-sample blocks from src into ring slots slot_first, +1, .. (mod 11);
-    // wave w moves the blocks w, w + 4, ..
-    auto dma = [&](const float *src, int slot_first, int nblk) {
-        for (int i = wave; i < nblk; i += 4) {
-            int slot = slot_first + i;
-            slot = slot >= kX2RingBlocks ? slot - kX2RingBlocks : slot;
-            lds_dma_16(src + 256 * i + 4 * lane, ring + 256 * slot);
-        }
-    };
-    if (c0 < c1)
-        dma(src_chunk, 0, (frames_left < FPC ? frames_left : FPC) + 3);
-
-    // -i W_1024^(lambda + 32 r) for the split, [lambda][r][re, im]: read once per pass, kept out of the registers
-    // (row stride 20 floats: the 16 lanes of a ds_read_b128 group then start in 16 different bank quads)
-    for (int i = tid; i < 32 * 16; i += kWave1024Threads)
-        tws_tab[kX2TwsStride * (i >> 4) + (i & 15)] = tab[(78 + (i & 15)) * 64 + (i >> 4)];
-    // per-lane constants
-    // W_32^(2 p + h), [h][p][re, im]: two rows, read as broadcasts
-    float *c32_tab = tws_tab + 32 * kX2TwsStride;
-    if (tid < 32)
-        c32_tab[tid] = tab[(62 + (tid & 15)) * 64 + 16 * (tid >> 4)];
-    v2f win[16], twA[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        win[j] = v2f{tab[(2 * j) * 64 + lane], tab[(2 * j + 1) * 64 + lane]};
-#pragma unroll
-    for (int k = 1; k < 16; ++k)
-        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
-    const int e1_rd_off = __float_as_int(tab[94 * 64 + lane]);           // complex index of the lane's 16 values
-    const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + e1_rd_off);
-    const unsigned ring_addr = lds_addr(ring) + 8u * (unsigned)l;
-
-    // frames ta (lanes 0-31) and ta + 1 (lanes 32-63) of the chunk whose block 8 it sits in slot s0 -> v
-    const int ta = 2 * wave;
-    auto read_frames = [&](v2f (&v)[16], int s0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned s = (unsigned)(s0 + ta + q) + (unsigned)f;
-            s = min(s, s - (unsigned)kX2RingBlocks);                                     // mod 11 (s < 22): one v_min_u32
-            const unsigned a = ring_addr + 1024u * s;
-            v[4 * q + 0] = lds_read_b64<0>(a);
-            v[4 * q + 1] = lds_read_b64<256>(a);
-            v[4 * q + 2] = lds_read_b64<512>(a);
-            v[4 * q + 3] = lds_read_b64<768>(a);
-        }
-    };
-    // Software pipeline over the chunks: the frames of chunk c + 1 are fetched from the ring while the rows of
-    // chunk c are staged out (the data registers are free by then, and the two LDS round trips - frames in,
-    // row image out - overlap), so the loop body starts with the frames already in registers.
-    //   top of the body      v = frames of chunk c
-    //   ... transform, split, magnitudes, row image ...
-    //   vmcnt(0) + barrier   every wave's LDS-DMA pieces of chunk c + 1 have landed (they were issued a whole
-    //                        chunk ago, in front of the previous rows' stores)
-    //   frame reads (c + 1), row-image reads (c), lgkmcnt(0), row stores (c)
-    //   barrier              every wave holds its frames: blocks 8 it + 8 .. + 15 are dead
-    //   LDS-DMA of chunk c + 2 onto them
-    int slot0 = 0;                                            // slot of block 8 it (first block of chunk c)
-    int it = 0;
-    v2f v[16];
-    bool active = false;                                      // wave-uniform: the wave has a frame in chunk c
-    if (c0 < c1) {
-        wait_vmcnt_le<0>();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                        // the first chunk's blocks (and the LDS tables) are in place
-        active = ta < (frames_left < FPC ? frames_left : FPC);
-        read_frames(v, 0);                                    // (a wave without a frame reads too: no branch around v)
-        lds_wait_16(v);
-        __builtin_amdgcn_s_barrier();
-        if (c0 + 1 < c1) {
-            const int nleft = frames_left - FPC;
-            dma(src_chunk + (FPC + 3) * HOP, 0, nleft < FPC ? nleft : FPC);
-        }
-    }
-    for (int c = c0; c < c1; ++c, ++it) {
-        const int prio_r = (int)(blockIdx.x >> 8) + (AA_X2_PRIO == 9 ? it : 0);      // (the step count of a chunk, 3 or 6, drops out mod 3)
-        x2_prio(0, prio_r);
-        const int nf = frames_left < FPC ? frames_left : FPC;
-        const bool vb = ta + 1 < nf;                          // lanes 32-63 hold a real frame
-        const bool has_next = c + 1 < c1;
-        const int nf_next = has_next ? (frames_left - FPC < FPC ? frames_left - FPC : FPC) : 0;
-        const bool active_next = ta < nf_next;
-        int slot_next = slot0 + FPC;
-        slot_next = slot_next >= kX2RingBlocks ? slot_next - kX2RingBlocks : slot_next;
-        float *lrow = nullptr;
-        int sh2 = 0;
-        // The per-lane LDS addresses of the body are re-derived from an opaque copy of the lane index every chunk
-        // (a dozen VALU operations): as loop invariants they would each hold a register for the kernel's lifetime,
-        // and the kernel sits at the 168-register edge of three waves per SIMD.
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int lf = ln >> 5, ll = ln & 31;
-        v2f *e1_wr = scr + lf * kX2FrameStride + (ll & 1) * kX2ParityStride + (ll >> 1);      // + 18 sigma(k1)
-        v2f *strip_wr = scr + lf * 264 + ll;                                  // + 32 (r - 8)
-        const v2f *strip_rd = scr + lf * 264 + 256 - ll;                      // - 32 r
-        const v4f *tws_rd = reinterpret_cast<const v4f *>(tws_tab + kX2TwsStride * ll);
-        const v4f *c32_rd = reinterpret_cast<const v4f *>(c32_tab + 16 * ((ln >> 4) & 1));
-        if (active) {
-            // ---- pass A ----
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = v[j] * win[j];
-            pk_dft16(v);
-            {
-                v2f t[16];
-#pragma unroll
-                for (int k = 1; k < 16; ++k)
-                    t[k] = pk_cmul_lo(v[k], twA[k]);
-                x2_prio(1, prio_r);
-                if (AA_X2_E1ILV) {
-                    // ---- E1 writes handed to the LDS as the twiddled values come out (four at a time), not as
-                    // one burst of sixteen behind the last FMA ----
-#pragma unroll
-                    for (int k0 = 0; k0 < 16; k0 += 4) {
-#pragma unroll
-                        for (int k = k0 ? k0 : 1; k < k0 + 4; ++k)
-                            v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
-#pragma unroll
-                        for (int k = k0; k < k0 + 4; ++k)
-                            e1_wr[18 * kX2E1Sigma[k]] = v[k];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 1; k < 16; ++k)
-                        v[k] = pk_cmul_hi(v[k], twA[k], t[k]);
-                    // ---- E1 ----
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        e1_wr[18 * kX2E1Sigma[k]] = v[k];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // (read order 0, 4, 1, 5, ..: the first butterflies of pass B pair register i with i + 8)
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = AA_X2_E1ORD ? (tt >> 1) + 4 * (tt & 1) : tt;
-                const v4f qv = e1_rd[t];
-                v[2 * t] = v2f{qv.x, qv.y};
-                v[2 * t + 1] = v2f{qv.z, qv.w};
-            }
-            __builtin_amdgcn_wave_barrier();
-            x2_prio(2, prio_r);
-            // ---- pass B + the radix-2 across the lane pair ----
-            pk_dft16(v);
-            hazard_fence16(v);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                float ex = v[2 * p].x, ey = v[2 * p].y, ox = v[2 * p + 1].x, oy = v[2 * p + 1].y;
-                xpose_pair_b4(ex, ox);
-                xpose_pair_b4(ey, oy);
-                v[2 * p] = v2f{ex, ey};
-                v[2 * p + 1] = v2f{ox, oy};
-            }
-            v2f z[16];                                        // z[r] = Z[lambda + 32 r]
-            {
-                const v4f ca = c32_rd[0], cb = c32_rd[1], cc = c32_rd[2], cd = c32_rd[3];
-                const v2f c32[8] = {v2f{ca.x, ca.y}, v2f{ca.z, ca.w}, v2f{cb.x, cb.y}, v2f{cb.z, cb.w},
-                                    v2f{cc.x, cc.y}, v2f{cc.z, cc.w}, v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};
-                v2f t[8];
-#pragma unroll
-                for (int p = 0; p < 8; ++p)
-                    t[p] = pk_cmul_lo(v[2 * p + 1], c32[p]);
-#pragma unroll
-                for (int p = 0; p < 8; ++p)
-                    t[p] = pk_cmul_hi(v[2 * p + 1], c32[p], t[p]);
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    z[p] = v[2 * p] + t[p];
-                    z[p + 8] = v[2 * p] - t[p];
-                }
-            }
-            // ---- partners Z[512 - k] through the strip ----
-            x2_prio(3, prio_r);
-#pragma unroll
-            for (int r = 8; r < 16; ++r)
-                strip_wr[32 * (r - 8)] = z[r];
-            if (ll == 0)
-                scr[lf * 264 + 256] = z[0];
-            __builtin_amdgcn_wave_barrier();
-            x2_prio(4, prio_r);
-            // ---- split + magnitudes, four pairs at a time (stage by stage inside a group); the row image
-            // sits behind the strips in the scratch, so a group's values are staged at once ----
-            sh2 = ta & 3;                                     // (8 c + ta) 513 mod 4: 0 or 2
-            lrow = reinterpret_cast<float *>(scr) + kX2RowImage + sh2 + lf * NB + ll;
-#pragma unroll
-            for (int g = 0; g < 8; g += 4) {
-                v2f prt[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    prt[j] = strip_rd[-32 * (g + j)];
-                const v4f twa = tws_rd[g / 2], twb = tws_rd[g / 2 + 1];
-                const v2f tws[4] = {v2f{twa.x, twa.y}, v2f{twa.z, twa.w}, v2f{twb.x, twb.y}, v2f{twb.z, twb.w}};
-                v2f se[4], so[4], st[4], re[4], im[4], pw[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    se[j] = pk_add_conj(z[g + j], prt[j]);
-                    so[j] = pk_sub_conj(z[g + j], prt[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    st[j] = pk_cmul_lo(so[j], tws[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    st[j] = pk_cmul_hi(so[j], tws[j], st[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    re[j] = pk_sum_diff_re(se[j], st[j]);
-                    im[j] = pk_sum_diff_im(se[j], st[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    pw[j] = re[j] * re[j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    pw[j] = im[j] * im[j] + pw[j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    lrow[32 * (g + j)] = bin_from_power<OUT>(pw[j].x, log_floor);
-                    lrow[512 - 2 * ll - 32 * (g + j)] = bin_from_power<OUT>(pw[j].y, log_floor);
-                }
-            }
-            const float m256 = bin_value<OUT>(2.0f * z[8].x, 2.0f * z[8].y, log_floor);   // lane lambda = 0 only
-            if (ll == 0)
-                lrow[256] = m256;
-        }
-        // ---- the frames of the next chunk come in while the rows of this one go out ----
-        // Order of the vector-memory operations of a wave: .. DMA(c + 1) | stores(c - 1) .. DMA(c + 2) | stores(c) ..
-        // - the rows are stored BEHIND the next LDS-DMA, so that waiting for a DMA (vmcnt retires in order) never
-        // waits for row stores: the wait below leaves exactly the kRowStores stores of the previous chunk in flight
-        // (none were issued yet in the first pass: full wait).
-        x2_prio(5, prio_r);
-        if (has_next && !(AA_X2_ABL & 1)) {
-            if (it == 0)
-                wait_vmcnt_le<0>();
-            else
-                wait_vmcnt_le<kRowStores>();
-            __builtin_amdgcn_s_barrier();                    // every wave's pieces of chunk c + 1 have landed
-        }
-        // Every wave reads, whether or not the next chunk exists or holds a frame for it (the addresses are valid
-        // either way, the values unused): branches around the sixteen data registers cost register copies at
-        // every merge.
-        read_frames(v, slot_next);
-        // the two rows leave as one piece (stft_wave1024_kernel's adjacent-frame scheme): image -> registers now,
-        // registers -> memory behind the barrier and the DMA
-        const float *lw = reinterpret_cast<const float *>(scr) + kX2RowImage;
-        float *gw = out_chunk + ta * NB - sh2;                // 16-byte aligned window of row a
-        const int eo = sh2 ? 2 : 1024;
-        const int hi = lane < 4 ? lane : 508 + lane;
-        v4f q0, q1, q2, q3;
-        v2f edge;
-        float hv = 0.0f;
-        if (active) {
-            __builtin_amdgcn_wave_barrier();
-            if (vb) {
-                const v4f *lw4 = reinterpret_cast<const v4f *>(lw + 2 * sh2) + lane;
-                q0 = lw4[0]; q1 = lw4[64]; q2 = lw4[128]; q3 = lw4[192];
-                edge = *reinterpret_cast<const v2f *>(lw + eo);
-            } else {
-                // ragged last chunk: only row a exists
-                q0 = *reinterpret_cast<const v4f *>(lw + 4 + 4 * lane);
-                q1 = *reinterpret_cast<const v4f *>(lw + 260 + 4 * (lane < 63 ? lane : 62));
-                hv = lw[lane < 8 ? hi : 0];
-            }
-        }
-        lds_wait_16(v);                                       // frames and row image are in registers
-        if (has_next && !(AA_X2_ABL & 1)) {
-            __builtin_amdgcn_s_barrier();                    // every wave holds its frames of chunk c + 1
-            if (c + 2 < c1) {
-                const int nleft = frames_left - 2 * FPC;
-                dma(src_chunk + (2 * FPC + 3) * HOP, slot_next, nleft < FPC ? nleft : FPC);
-            }
-        }
-        if (active && !(AA_X2_ABL & 2)) {
-            if (vb) {
-                v4f *gw4 = reinterpret_cast<v4f *>(gw + 2 * sh2) + lane;
-                row_store(q0, gw4);
-                row_store(q1, gw4 + 64);
-                row_store(q2, gw4 + 128);
-                row_store(q3, gw4 + 192);
-                if (lane == 0)
-                    *reinterpret_cast<v2f *>(gw + eo) = edge;
-            } else {
-                row_store(q0, reinterpret_cast<v4f *>(gw + 4 + 4 * lane));
-                if (lane < 63)
-                    row_store(q1, reinterpret_cast<v4f *>(gw + 260 + 4 * lane));
-                // head floats sh2..3 (lanes 0-3) and tail floats 512..512+sh2 (lanes 4-7)
-                if (lane < 4 ? lane >= sh2 : (lane < 8 && lane - 4 <= sh2))
-                    gw[hi] = hv;
-            }
-        }
-        active = active_next;
-        slot0 = slot_next;
-        src_chunk += FPC * HOP;
-        out_chunk += FPC * NB;
-        frames_left -= FPC;
-    }
-}
-
 // ---------------------------------------------------- wave-per-frame, n_fft = 2048 --
 // The tuner geometry of the reference (window 2048, hop 512: src/audio_io/stft.rs:169-170).
 // 1024 complex points per frame = one radix-2 split over two 512-point transforms that one
@@ -2567,7 +1464,8 @@ void stft_wave1024x2_kernel(
 // chunk buffers of that kernel for any hop, a ring with the DMA two chunks ahead (RING == 2, below)
 // for the tuner geometry itself.  Table rows ([92][64]): 0..31 0.5*w[4(64j+lane)+c] (row 4j+c),
 // 32..45 W_512^(lane k), 46..59 W_64^((lane>>3) k), 60..75 W_1024^(lane+64kb),
-// 76..91 -i W_2048^(lane+64kb); behind them the float4 tables of the RING == 1 experiment.
+// 76..91 -i W_2048^(lane+64kb); behind them [8][64] float4 of the window and [4][64] float4 each of the combine
+// and the split twiddles (two per float4), which stft_wave2048_mel_kernel streams per frame.
 __device__ __forceinline__ void fft512_pass_a(v2f (&v)[8], const v2f (&twA)[8])
 {
     pk_dft8(v);
@@ -2600,59 +1498,11 @@ __device__ __forceinline__ void fft512_pass_bc(v2f (&v)[8], const v2f (&twB)[8])
     pk_dft8(v);
 }
 
-// Hand-issued global load of a lane's 16 bytes at sbase (uniform) + voff (bytes) + OFF; valid after
-// vm_wait_tied8 (same discipline as the hand-issued LDS loads: nothing may copy the register first).
-template <int OFF>
-__device__ __forceinline__ v4f gload4_issue(const float *sbase, unsigned voff)
-{
-    v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-    return r;
-}
-template <int N>   // at most N newer vector-memory operations in flight
-__device__ __forceinline__ void vm_wait_tied8(v4f (&w)[8])
-{
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
-                 : "n"(AA_SAFE_WAITS ? 0 : N)
-                 : "memory");
-}
-// RING == 1 (hop 512, 4 frames per chunk; an experiment that lost, built with -DAA_RING_COMPLEX=1 only,
-// DESIGN.md section 8): FOUR workgroups per CU instead of three.
-//  * staging: one ring of 22 blocks of 256 floats (22.5 KB) instead of two chunk buffers (28.7 KB): a
-//    chunk is blocks [8 i, 8 i + 14) of the workgroup's sample run, block b lives in slot b mod 22, the
-//    8 new blocks of chunk i + 1 overwrite blocks 8 i - 8 .. 8 i - 1 (dead since the chunk-top barrier);
-//    one LDS-DMA instruction moves one block, a wave moves exactly two per full chunk; a frame's eight
-//    ds_read_b128 are eight consecutive blocks.  39.4 KB per workgroup.
-//  * registers: the window (32), the combine and the split twiddles (16 + 16) are not resident but
-//    streamed from the per-lane table (L1 / L2) every frame: <= 128 VGPRs.  The window loads are
-//    issued BEFORE the chunk's LDS-DMA and waited for with a counted vmcnt (vmcnt retires in order:
-//    waiting for a load issued after the DMA would wait for the DMA); the twiddles are fetched in
-//    mid-frame, when the DMA issued at the chunk top has long landed.
-constexpr int kRingBlocks = 22;
-#ifndef AA_R_TWA
-#define AA_R_TWA 1
-#endif
-#ifndef AA_R_TWB
-#define AA_R_TWB 0
-#endif
-#ifndef AA_R_WC
-#define AA_R_WC 0
-#endif
-#ifndef AA_W2048_PIPE
-#define AA_W2048_PIPE 0      // RING == 2 magnitude-type rows: the frame of chunk c + 1 is read from the ring while the row of chunk c is staged out
-#endif
 #ifndef AA_W2048_DMA_LATE
 #define AA_W2048_DMA_LATE 1  // r3: -0.4 % (75.0 -> 74.7 us), same order of the vector-memory operations (DMA, then the chunk's stores)
 #endif
-#ifndef AA_WSMALL_DMA_LATE
-#define AA_WSMALL_DMA_LATE 0
-#endif
 #ifndef AA_WSMALL_PRIO
 #define AA_WSMALL_PRIO 0     // stft_wave_small_kernel: 0 one rotation step per frame group; ab: level a from the group's top, b behind its exchange
-#endif
-#ifndef AA_W2048_PRIO_MEL
-#define AA_W2048_PRIO_MEL 0  // fused mel rows: 0 the three-level rotation, 1 priority by phase (3 top, 2 behind the exchanges, 1 split, 0 gather)
 #endif
 #ifndef AA_W2048_PRIO
 #define AA_W2048_PRIO 210    // magnitude-type rows: 0 the four-level rotation; abc: priority by phase, the same in every workgroup - level a
@@ -2661,18 +1511,16 @@ constexpr int kRingBlocks = 22;
                              // HBM-sourced samples); two levels do nothing; complex rows and the fused mel rows lose with it (6 % at
                              // log-mel) and keep their rotations; the 1024 kernel (four waves per SIMD) is level with its rotation.
 #endif
-#ifndef AA_R_TWS
-#define AA_R_TWS 0
-#endif
-// RING == 2 (shipped for the tuner geometry): the ring alone, 30 blocks (block b of the workgroup's
-// sample run in slot b mod 30), with the LDS-DMA running TWO chunks ahead (three workgroups per CU,
-// constants resident as in the plain variant).  With four frames per chunk and three workgroups per
-// CU a chunk lasts ~1.7 us - about one HBM round trip under load - so the one-chunk-ahead DMA of the
-// plain variant arrives late whenever the samples come from HBM rather than the Infinity Cache; the
-// fused mel variants, whose streamed weights are waited for in mid-frame (vmcnt retires in order: that
-// wait includes every older DMA), issue the DMA behind the gather instead of at the chunk top.
-template <int OUT, bool WIDE, int NS = 0, int RING = 0>   // NS: steps of the streamed mel schedule (kLogMelR only)
-__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(RING == 1 ? 4 : 3, RING == 1 ? 4 : 3)))
+// RING == 2 (the tuner geometry: hop 512, 4 frames per chunk; magnitude-type and complex rows): the samples are
+// staged in a ring of 30 blocks of 256 floats instead of two chunk buffers - a chunk is blocks [8 i, 8 i + 14) of
+// the workgroup's sample run, block b lives in slot b mod 30, one LDS-DMA instruction moves one block, a wave
+// moves exactly two per full chunk, a frame's eight ds_read_b128 are eight consecutive blocks - with the LDS-DMA
+// running TWO chunks ahead.  With four frames per chunk and three workgroups per CU a chunk lasts ~1.7 us - about
+// one HBM round trip under load - so the one-chunk-ahead DMA of the two-buffer variant (RING == 0) arrives late
+// whenever the samples come from HBM rather than the Infinity Cache.  (The four-workgroup variant with a 22-block
+// ring and streamed constants, RING == 1 of r2, lost everywhere: tools/experiments/r04_removed_variants.diff.)
+template <int OUT, bool WIDE, int RING = 0>
+__global__ __launch_bounds__(kWave1024Threads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void stft_wave2048_kernel(
     const float *__restrict__ x, float *__restrict__ out, const float *__restrict__ tab,
     int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg, int64_t n_chunks,
@@ -2681,7 +1529,7 @@ void stft_wave2048_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, lane0 = lane;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int vgrid, vblock;
     {
@@ -2690,9 +1538,9 @@ void stft_wave2048_kernel(
         x += in_off;
         out += out_off;
     }
-    constexpr bool STREAM = RING == 1;               // constants streamed, four workgroups per CU
-    constexpr int RB = RING == 2 ? 30 : kRingBlocks;  // ring blocks
-    constexpr int DEPTH = RING == 2 ? 2 : 1;         // chunks the DMA runs ahead
+    static_assert(RING == 0 || RING == 2, "two chunk buffers or the 30-block ring");
+    constexpr int RB = 30;                           // ring blocks
+    constexpr int DEPTH = 2;                         // chunks the ring's DMA runs ahead
     if (RING) {
         hop = 512;
         frames_per_wg = 4;
@@ -2704,18 +1552,16 @@ void stft_wave2048_kernel(
     const int stage_dwords = RING ? RB * 256 : 2 * max_span;
     v2f *scr = reinterpret_cast<v2f *>(smem + stage_dwords + wave * kWave1024ScratchDwords);
     constexpr int NB = 1025;
-    constexpr bool MEL = OUT == kLogMel || OUT == kLogMelR;
+    constexpr bool MEL = OUT == kLogMel;
+    static_assert(!(MEL && RING), "the log-mel rows of the tuner geometry are stft_wave2048_mel_kernel's");
     constexpr bool kPhasePrio = AA_W2048_PRIO != 0 && (OUT == kMag || OUT == kPower || OUT == kLogPower);
-    // software pipeline over the chunks (see the hook in the row staging below): the chunk-top wait and barrier move to the
-    // tail of the previous chunk's body, in front of the frame reads of the next one
-    constexpr bool kPipe = AA_W2048_PIPE && RING == 2 && !MEL && RING != 1 && WIDE && OUT != kComplex;
     // global stores a wave issues for its ONE row of a full 4-frame chunk (see stft_wave1024_kernel)
     constexpr int kRowStoresPerChunk = OUT == kComplex ? (WIDE ? 9 : 17)      // 8 dwordx4 + 1 dwordx2 | 17 dwordx2
                                        : WIDE          ? 5                    // 4 dwordx4 + head / tail dword
                                                        : 17;                  // 17 dwords
     const int COLS = (OUT == kComplex) ? 2 * NB : MEL ? sch.n_mels : NB;
     float *melpar = smem + stage_dwords + 4 * kWave1024ScratchDwords;
-    float *melstage = melpar + (RING && OUT == kLogMelR ? 0 : kMelParTableDwords) + wave * kMelStageDwords;
+    float *melstage = melpar + kMelParTableDwords + wave * kMelStageDwords;
     if (OUT == kLogMel)
         for (int i = tid; i < kMelParTableDwords; i += kWave1024Threads)
             melpar[i] = mel_par[i];
@@ -2763,67 +1609,37 @@ void stft_wave2048_kernel(
 
     v4f win[8];
     v2f twA[8], twB[8], wc[8], tws[8];
-    if (!STREAM) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
-                         tab[(4 * j + 3) * 64 + lane]};
-    }
-    // RING: which twiddle sets stay resident (the others are streamed per frame)
-    constexpr bool kResA = !STREAM || AA_R_TWA, kResB = !STREAM || AA_R_TWB, kResC = !STREAM || AA_R_WC,
-                   kResS = !STREAM || AA_R_TWS;
+    for (int j = 0; j < 8; ++j)
+        win[j] = v4f{tab[(4 * j) * 64 + lane], tab[(4 * j + 1) * 64 + lane], tab[(4 * j + 2) * 64 + lane],
+                     tab[(4 * j + 3) * 64 + lane]};
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        if (kResA)
-            twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
-        if (kResB)
-            twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
+        twA[k] = v2f{tab[(32 + 2 * (k - 1)) * 64 + lane], tab[(33 + 2 * (k - 1)) * 64 + lane]};
+        twB[k] = v2f{tab[(46 + 2 * (k - 1)) * 64 + lane], tab[(47 + 2 * (k - 1)) * 64 + lane]};
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        if (kResC)
-            wc[j] = v2f{tab[(60 + 2 * j) * 64 + lane], tab[(61 + 2 * j) * 64 + lane]};
-        if (kResS)
-            tws[j] = v2f{tab[(76 + 2 * j) * 64 + lane], tab[(77 + 2 * j) * 64 + lane]};
+        wc[j] = v2f{tab[(60 + 2 * j) * 64 + lane], tab[(61 + 2 * j) * 64 + lane]};
+        tws[j] = v2f{tab[(76 + 2 * j) * 64 + lane], tab[(77 + 2 * j) * 64 + lane]};
     }
-    // RING: the streamed per-lane tables behind the 92 rows: [8][64] float4 of the window, then [4][64]
-    // float4 each of: two combine twiddles (j = 2 i, 2 i + 1), two split twiddles, two pass-A twiddles
-    // (k = 2 i, 2 i + 1; k = 0 unused), two pass-B twiddles
-    const float *win4 = tab + kWave2048Rows * 64, *ct4 = win4 + 8 * 64 * 4, *ab4 = ct4 + 8 * 64 * 4;
-    v4f twA4[4];                                     // RING: pass-A twiddles as loaded
 
     v2f *e1_wr = scr + 66 * (lane & 7) + (lane >> 3);
     const v4f *e1_rd = reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3));
 
-    int dma_prev = 0;                                   // RING == 2: DMA instructions of the last round
-    v4f raw[8];                                         // RING: the wave's frame as it comes from the ring (kPipe: loop carried)
-    if (kPipe && c0 < c1) {
-        wait_vmcnt_le<0>();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                  // the first two chunks have landed
-        const int s0 = (2 * wave) % RB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                   // (a wave without a frame reads too: no branch around the registers)
-            const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
-            raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane0];
-        }
-    }
+    int dma_prev = 0;                                   // RING: DMA instructions of the last round
+    v4f raw[8];                                         // RING: the wave's frame as it comes from the ring
     for (int c = c0; c < c1; ++c) {
         const int cur = (c - c0) & 1;
-        if (!kPipe) {
         // counted wait as in stft_wave1024_kernel: with 4 frames per chunk every wave stored one
         // row in the previous (full) chunk, after issuing this chunk's DMA loads
         if (c == c0 || frames_per_wg != 4)
             wait_vmcnt_le<0>();
-        else if (RING == 2) {
+        else if (RING) {
             // the blocks of this chunk were issued two DMA rounds ago: behind them sit the stores of
             // two (full) chunks and the two DMA instructions of the last round
             if (c - c0 < 2 || dma_prev != 2)
                 wait_vmcnt_le<0>();
-            else if (MEL && sch.n_mels > 64)             // (DMA behind the stores: one chunk's stores + one round)
-                wait_vmcnt_le<2 + 2>();
-            else if (MEL)
-                wait_vmcnt_le<1 + 2>();
             else
                 wait_vmcnt_le<2 * kRowStoresPerChunk + 2>();
         } else if (MEL && sch.n_mels > 64)
@@ -2834,47 +1650,23 @@ void stft_wave2048_kernel(
             wait_vmcnt_le<kRowStoresPerChunk>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        }
         const int prio_step = (int)(blockIdx.x >> 8) + (MEL ? 3 : 2) * (c - c0);   // see rotate_wave_priority[3]
         if (kPhasePrio)
             __builtin_amdgcn_s_setprio(AA_W2048_PRIO >= 1000 ? (AA_W2048_PRIO / 1000) % 10 : (AA_W2048_PRIO / 100) % 10);
-        else if (AA_W2048_PRIO_MEL && MEL)
-            __builtin_amdgcn_s_setprio(3);
         else if (MEL)
             rotate_wave_priority3(prio_step);
         else
             rotate_wave_priority(prio_step);
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
-        int n_dma = -1;                                  // STREAM: DMA instructions issued behind the window loads
-        if (STREAM && wave < nf) {
-            unsigned voff = 16u * (unsigned)lane;
-            asm volatile("" : "+v"(voff));               // (not a loop invariant worth a register)
-            win[0] = gload4_issue<0>(win4, voff);
-            win[1] = gload4_issue<1024>(win4, voff);
-            win[2] = gload4_issue<2048>(win4, voff);
-            win[3] = gload4_issue<3072>(win4, voff);
-            win[4] = gload4_issue<0>(win4 + 1024, voff);
-            win[5] = gload4_issue<1024>(win4 + 1024, voff);
-            win[6] = gload4_issue<2048>(win4 + 1024, voff);
-            win[7] = gload4_issue<3072>(win4 + 1024, voff);
-            if (!kResA) {
-                twA4[0] = gload4_issue<0>(ab4, voff);
-                twA4[1] = gload4_issue<1024>(ab4, voff);
-                twA4[2] = gload4_issue<2048>(ab4, voff);
-                twA4[3] = gload4_issue<3072>(ab4, voff);
-            }
-        }
-        // AA_W2048_DMA_LATE (RING == 2, magnitude / complex rows): the DMA of the chunk after next is issued BEHIND the
-        // frame reads of this chunk (its scalar address loop then runs under their LDS round trip) instead of in front
-        constexpr bool kDmaLate = AA_W2048_DMA_LATE && RING == 2 && !MEL && !STREAM;
+        // AA_W2048_DMA_LATE (RING): the DMA of the chunk after next is issued BEHIND the frame reads of this chunk (its
+        // scalar address loop then runs under their LDS round trip) instead of in front
+        constexpr bool kDmaLate = AA_W2048_DMA_LATE && RING;
         bool dma_due = false;
         if (RING) {
-            if (kPipe)
-                dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));     // (the frame is in registers already)
-            else if (kDmaLate && wave < nf)
+            if (kDmaLate && wave < nf)
                 dma_due = true;
-            else if (!(RING == 2 && MEL))                     // (those: behind the gather)
-                dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
+            else
+                dma_prev = ring_dma(blocks_end(c - c0 + DEPTH));
         } else if (c + 1 < c1) {
             const int nleft = frames_left - frames_per_wg;
             stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
@@ -2883,40 +1675,18 @@ void stft_wave2048_kernel(
         const v4f *buf = reinterpret_cast<const v4f *>(smem + cur * max_span) + lane;
 
         for (int t = wave; t < nf; t += 4) {
-            // RING: per-lane addresses come from opaque copies of the lane index - as loop invariants
-            // they are hoisted out of the chunk loop, held across the FFT phases and spilled
-            int lane = lane0;
-            if (STREAM)
-                asm volatile("" : "+v"(lane));
             v2f e[8], o[8];
             if (RING) {
                 // frame t starts at block 8 (c - c0) + 2 t; read j is block + j
                 const int s0 = (8 * (c - c0) + 2 * t) % RB;
-                if (!kPipe) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
-                        raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int sj = s0 + j < RB ? s0 + j : s0 + j - RB;
+                    raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
                 }
                 if (kDmaLate && dma_due) {
-                    dma_prev = n_dma = ring_dma(blocks_end(c - c0 + DEPTH));
+                    dma_prev = ring_dma(blocks_end(c - c0 + DEPTH));
                     dma_due = false;
-                }
-                if (!STREAM) {
-                } else if (n_dma == 2)
-                    vm_wait_tied8<2>(win);
-                else if (n_dma == 1)
-                    vm_wait_tied8<1>(win);
-                else
-                    vm_wait_tied8<0>(win);
-                if (!kResA) {
-                    asm volatile("" : "+v"(twA4[0]), "+v"(twA4[1]), "+v"(twA4[2]), "+v"(twA4[3])::"memory");   // same wait
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        twA[2 * i] = v2f{twA4[i].x, twA4[i].y};
-                        twA[2 * i + 1] = v2f{twA4[i].z, twA4[i].w};
-                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -2933,46 +1703,19 @@ void stft_wave2048_kernel(
                     o[j] = v2f{sx.z, sx.w};
                 }
             }
-            int ln = lane;
-            if (!kResB) {
-                // pass-B twiddles of this frame: in flight during pass A
-                asm volatile("" : "+v"(ln));
-                const v4f *bp = reinterpret_cast<const v4f *>(ab4) + 4 * 64 + ln;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const v4f q = bp[64 * i];
-                    twB[2 * i] = v2f{q.x, q.y};
-                    twB[2 * i + 1] = v2f{q.z, q.w};
-                }
-            }
-            v2f *e1w = STREAM ? scr + 66 * (lane & 7) + (lane >> 3) : e1_wr;
-            const v4f *e1r = STREAM ? reinterpret_cast<const v4f *>(scr + 8 * (lane & 7) + 66 * (lane >> 3)) : e1_rd;
             fft512_pass_a(e, twA);
-            fft512_exchange1(e, e1w, e1r);
+            fft512_exchange1(e, e1_wr, e1_rd);
             if (kPhasePrio && AA_W2048_PRIO >= 1000)
                 __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 100) % 10);
             fft512_pass_a(o, twA);
-            fft512_exchange1(o, e1w, e1r);
+            fft512_exchange1(o, e1_wr, e1_rd);
             if (kPhasePrio)
                 __builtin_amdgcn_s_setprio((AA_W2048_PRIO / 10) % 10);
-            else if (AA_W2048_PRIO_MEL && MEL)
-                __builtin_amdgcn_s_setprio(2);
             else if (MEL)
                 rotate_wave_priority3(prio_step + 1);
             else
                 rotate_wave_priority(prio_step + 1);
             fft512_pass_bc(e, twB);
-            if (!kResC) {
-                // combine twiddles of this frame: in flight during passes B and C of the odd half
-                asm volatile("" : "+v"(ln));
-                const v4f *cp = reinterpret_cast<const v4f *>(ct4) + ln;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const v4f q = cp[64 * j];
-                    wc[2 * j] = v2f{q.x, q.y};
-                    wc[2 * j + 1] = v2f{q.z, q.w};
-                }
-            }
             fft512_pass_bc(o, twB);
             // radix-2 combine: zl[kb] = Z[lane + 64 kb], zh[kb] = Z[512 + lane + 64 kb]
             v2f zl[8], zh[8];
@@ -2981,17 +1724,6 @@ void stft_wave2048_kernel(
                 v2f tt = pk_cmul(o[j], wc[j]);
                 zl[j] = e[j] + tt;
                 zh[j] = e[j] - tt;
-            }
-            if (!kResS) {
-                // split twiddles: in flight during the strip round trip
-                asm volatile("" : "+v"(ln));
-                const v4f *sp = reinterpret_cast<const v4f *>(ct4) + 4 * 64 + ln;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const v4f q = sp[64 * j];
-                    tws[2 * j] = v2f{q.x, q.y};
-                    tws[2 * j + 1] = v2f{q.z, q.w};
-                }
             }
             // strip[i] = Z[512 + i], i = 0..511; strip[512] = Z[1024] := Z[0]
 #pragma unroll
@@ -3007,10 +1739,6 @@ void stft_wave2048_kernel(
             __builtin_amdgcn_wave_barrier();
             if (kPhasePrio)
                 __builtin_amdgcn_s_setprio(AA_W2048_PRIO % 10);
-            if (AA_W2048_PRIO_MEL && MEL)
-                __builtin_amdgcn_s_setprio(1);
-            if (STREAM)
-                asm volatile("" : "+v"(lane));
 
             float *row = out_chunk + t * COLS;
             // complex rows: xk / xm = X[k], conj(X[1024-k]); the other kinds: pw = (|X[k]|^2, |X[1024-k]|^2)
@@ -3106,14 +1834,8 @@ void stft_wave2048_kernel(
                     if (lane == 0)
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
-                    if (AA_W2048_PRIO_MEL)
-                        __builtin_amdgcn_s_setprio(0);
-                    else
-                        rotate_wave_priority3(prio_step + 2);
-                    if (OUT == kLogMelR)
-                        mel_reduce_streamed<(NS > 0 ? NS : 2)>(lds_addr(lrow), mel_par, sch, melstage);
-                    else
-                        mel_reduce<1>(lrow, NB, melpar, sch, melstage);
+                    rotate_wave_priority3(prio_step + 2);
+                    mel_reduce<1>(lrow, NB, melpar, sch, melstage);
                     mel_store<1>(melstage, sch, log_floor, row, nullptr, false);
                 } else if (WIDE) {
                     const int sh = (row0 + t) & 3;     // 1025 = 1 (mod 4): same shift rule as 513
@@ -3126,27 +1848,6 @@ void stft_wave2048_kernel(
                     if (lane == 0)
                         lrow[512] = m512;
                     __builtin_amdgcn_wave_barrier();
-                    if (kPipe) {
-                        // .. DMA(c + 1) | stores(c - 1) | DMA(c + 2) .. : leave the row stores of the previous chunk and
-                        // the DMA instructions of this chunk's round in flight (the first chunk: chunk c0 + 1 landed in
-                        // the prologue); the barrier also says that every wave is done with the frames of chunk c
-                        if (c + 1 < c1) {
-                            if (c == c0) {
-                            } else if (dma_prev == 2)
-                                wait_vmcnt_le<kRowStoresPerChunk + 2>();
-                            else if (dma_prev == 1)
-                                wait_vmcnt_le<kRowStoresPerChunk + 1>();
-                            else
-                                wait_vmcnt_le<kRowStoresPerChunk>();
-                            __builtin_amdgcn_s_barrier();
-                        }
-                        const int s1 = (8 * (c - c0 + 1) + 2 * t) % RB;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int sj = s1 + j < RB ? s1 + j : s1 + j - RB;
-                            raw[j] = reinterpret_cast<const v4f *>(smem + 256 * sj)[lane];
-                        }
-                    }
                     const float *lw = reinterpret_cast<const float *>(scr);
                     float *gw = row - sh;
                     // window floats 4..1023 as 4 dwordx4 pieces (the last one 63 lanes), head
@@ -3175,8 +1876,6 @@ void stft_wave2048_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (RING == 2 && MEL)
-            dma_prev = ring_dma(blocks_end(c - c0 + DEPTH));
         src_chunk += src_stride;
         out_chunk += out_stride;
         frames_left -= frames_per_wg;
@@ -3584,16 +2283,11 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
         __builtin_amdgcn_s_barrier();
         int prio_step = (int)(blockIdx.x >> 8) + 2 * (c - c0);   // see rotate_wave_priority; + 1 per group
         const int nf = frames_left < frames_per_wg ? frames_left : frames_per_wg;
-        // AA_WSMALL_DMA_LATE: the next chunk's LDS-DMA behind the frame reads of the wave's first group (as in stft_wave1024_kernel;
-        // measured +-0 here - 68.4 against 68.7 us at 256 / 64 - and left off)
-        bool dma_due = false;
+        // (the next chunk's LDS-DMA behind the frame reads of the wave's first group, as in stft_wave1024_kernel, measured +-0
+        // here - 68.4 against 68.7 us at 256 / 64)
         if (c + 1 < c1) {
-            if (AA_WSMALL_DMA_LATE && FPW * wave < nf)
-                dma_due = true;
-            else {
-                const int nleft = frames_left - frames_per_wg;
-                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
-            }
+            const int nleft = frames_left - frames_per_wg;
+            stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
         }
         // register j <- block (j + rotA) mod 8: blocks are N / 2 bytes apart; one base for j = 0..6,
         // the wrapped one for j = 7
@@ -3616,11 +2310,6 @@ __global__ __launch_bounds__(kWave1024Threads) void stft_wave_small_kernel(
             v[2] = small_frame_read<N, 256>(fr); v[3] = small_frame_read<N, 384>(fr);
             v[4] = small_frame_read<N, 512>(fr); v[5] = small_frame_read<N, 640>(fr);
             v[6] = small_frame_read<N, 768>(fr); v[7] = small_frame_read<N, 896>(fr - wrap7);
-            if (dma_due) {
-                const int nleft = frames_left - frames_per_wg;
-                stage(src_chunk + src_stride, nleft < frames_per_wg ? nleft : frames_per_wg, cur ^ 1);
-                dma_due = false;
-            }
             lds_wait_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -4215,32 +2904,10 @@ __global__ void irfft_kernel(const float *__restrict__ spec, float *__restrict__
 }  // namespace
 
 // ------------------------------------------------------------------- launchers --
-#ifndef AA_ABLATE   // the diagnostic build (tools/ablate_w1024.hip) drives the kernel itself
 // Persistent grid: resident workgroups per CU (occupancy API) x CUs.  There is no
 // inter-workgroup dependency, so an over- or under-estimate only changes speed.
-// Experiment knobs of the launchers (AA_GRID_MULT, AA_GRID_SET, AA_W2048_RING, AA_LDS_PAD) exist only in
-// libraries built with -DAA_EXPERIMENTS=1 (tools/probe_bimodal_grid.py, tools/profile_ring.sh): the shipped
-// library never reads the process environment on a launch.  Values outside [lo, hi] are ignored.
-#ifndef AA_EXPERIMENTS
-#define AA_EXPERIMENTS 0
-#endif
-static int experiment_knob(const char *name, int dflt, int lo, int hi)
-{
-#if AA_EXPERIMENTS
-    if (const char *e = getenv(name)) {
-        char *end = nullptr;
-        const long v = strtol(e, &end, 10);
-        if (end != e && *end == '\0' && v >= lo && v <= hi)
-            return (int)v;
-    }
-#else
-    (void)name;
-    (void)lo;
-    (void)hi;
-#endif
-    return dflt;
-}
-
+// Experiment knobs of the launchers (AA_GRID_MULT, AA_GRID_SET, AA_W2048_RING, AA_LDS_PAD: experiment_knob, aa_internal.hpp)
+// exist only in libraries built with -DAA_EXPERIMENTS=1 (tools/probe_bimodal_grid.py, tools/profile_ring.sh).
 template <typename K>
 static int persistent_grid(K kernel, size_t lds)
 {
@@ -4274,34 +2941,26 @@ template <int K>
 static hipError_t launch_wave1024_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
-                                       const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch)
+                                       const MelSched &sch, const Channels &ch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kMfccR ? 2 : (K == kLogMel || K == kLogMelR) ? 1 : 0);
+    const size_t lds = wave1024_lds_bytes(frames_per_wg, hop, K == kLogMel ? 1 : 0);
     static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
     static thread_local size_t cached_lds = 0;
     if (cached_grid == 0 || cached_lds != lds) {
-        cached_grid = persistent_grid(stft_wave1024_kernel<K, 0, true>, lds);
+        cached_grid = persistent_grid(stft_wave1024_kernel<K, true>, lds);
         cached_lds = lds;
     }
     // AA_GRID_SET (experiment builds): another number of persistent workgroups
     const int64_t want = experiment_knob("AA_GRID_SET", cached_grid, 1, 1 << 16);
     const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
-#ifndef AA_V_ABL
-#define AA_V_ABL 0      // experiments: an ablation / variant mask of stft_wave1024_kernel in the product launcher
-#endif
-    constexpr bool kPipeKind = AA_V_PIPE && AA_V_PAIR && !AA_V_ILV && !(AA_V_ABL & 8) && (K == kMag || K == kPower || K == kLogPower);
-    if (wide && kPipeKind && frames_per_wg == 8)
-        hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true, kPipeKind>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
-                           ch.n, ch.in_stride, ch.out_stride);
-    else if (wide)
-        hipLaunchKernelGGL((stft_wave1024_kernel<K, AA_V_ABL, true>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
+    if (wide)
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, true>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch,
                            ch.n, ch.in_stride, ch.out_stride);
     else
-        hipLaunchKernelGGL((stft_wave1024_kernel<K, 0, false>), grid, block, lds, stream, x, out, table,
-                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, dct_tab, n_mfcc,
+        hipLaunchKernelGGL((stft_wave1024_kernel<K, false>), grid, block, lds, stream, x, out, table,
+                           frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch,
                            ch.n, ch.in_stride, ch.out_stride);
     return hipGetLastError();
 }
@@ -4329,18 +2988,15 @@ static hipError_t launch_wave1024_mel_kind(const float *x, float *out, const flo
 }
 
 #ifdef AA_TU_MFCC
-// aa_kernels_mfcc.hip: this file once more, for the fused MFCC instantiation of stft_wave1024_kernel alone, compiled with
-// -mllvm -amdgpu-sched-strategy=max-ilp (r3: -2.5 % for that kernel, 94.9 -> 92.6 us; as a flag of the whole library it makes nine
+// aa_kernels_mfcc.hip: this file once more, for the fused MFCC instantiation of stft_wave1024_mel_kernel alone, compiled with
+// -mllvm -amdgpu-sched-strategy=max-ilp (r3: -2.5 % for the fused MFCC kernel of that round; as a flag of the whole library it makes
 // fallback instantiations of the 2048 kernel spill and costs the 256 kernel a wave per SIMD, csrc/Makefile).
-hipError_t launch_wave1024_mfcc(bool mfma_mel, const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
-                                int frames_per_wg, float log_floor, hipStream_t stream, const float *mel_par,
-                                const MelSched &sch, const float *dct_tab, int n_mfcc, const Channels &ch)
+hipError_t launch_wave1024_mfcc(const float *x, float *out, const float *table, int64_t frame_begin, int64_t n_frames, int hop,
+                                float log_floor, hipStream_t stream, const float *mel_par, const MelSched &sch,
+                                const float *dct_tab, int n_mfcc, const Channels &ch)
 {
-    if (mfma_mel)
-        return launch_wave1024_mel_kind<kMfccM>(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch,
-                                                dct_tab, n_mfcc, ch);
-    return launch_wave1024_kind<kMfccR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream,
-                                        mel_par, sch, dct_tab, n_mfcc, ch);
+    return launch_wave1024_mel_kind<kMfccM>(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch, dct_tab,
+                                            n_mfcc, ch);
 }
 #else
 hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float *table,
@@ -4356,106 +3012,53 @@ hipError_t launch_wave1024(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
-    if ((out_kind == kLogMelR || out_kind == kMfccR) &&
-        (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelResidentSteps1024 || frames_per_wg != 8))
-        return hipErrorInvalidValue;
     if ((out_kind == kLogMelM || out_kind == kMfccM) &&
         (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelMfmaSteps || frames_per_wg != 8 || sch.n_mels < 16 ||
          sch.n_mels > kMelMaxMels || (sch.n_mels & 3)))
         return hipErrorInvalidValue;
     if (out_kind == kLogMelM && (reinterpret_cast<uintptr_t>(out) & 15u))   // dwordx4 row pieces
         return hipErrorInvalidValue;
-    if ((out_kind == kMfccR || out_kind == kMfccM) &&
-        (!dct_tab || n_mfcc < 1 || n_mfcc > 16 * kMfccTiles || sch.n_mels > kMelMaxMels))
+    if (out_kind == kMfccM && (!dct_tab || n_mfcc < 1 || n_mfcc > 16 * kMfccTiles))
         return hipErrorInvalidValue;
     // aligned nontemporal row stores need a 16-byte-aligned output buffer
     const bool wide = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     switch (out_kind) {
     case kComplex:
-        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+        return launch_wave1024_kind<kComplex>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kMag:
-        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+        return launch_wave1024_kind<kMag>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kPower:
-        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+        return launch_wave1024_kind<kPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogPower:
-        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+        return launch_wave1024_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogMel:
-        return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
-    case kLogMelR:
-        return launch_wave1024_kind<kLogMelR>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, nullptr, 0, ch);
+        return launch_wave1024_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogMelM:
         return launch_wave1024_mel_kind<kLogMelM>(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch, nullptr, 0, ch);
-    case kMfccR:   // built in a translation unit of its own (aa_kernels_mfcc.hip: another scheduler strategy)
-    case kMfccM:
-        return launch_wave1024_mfcc(out_kind == kMfccM, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream,
-                                    mel_par, sch, dct_tab, n_mfcc, ch);
+    case kMfccM:   // built in a translation unit of its own (aa_kernels_mfcc.hip: another scheduler strategy)
+        return launch_wave1024_mfcc(x, out, table, frame_begin, n_frames, hop, log_floor, stream, mel_par, sch, dct_tab, n_mfcc, ch);
     default:
         return hipErrorInvalidValue;
     }
 }
 
 template <int K>
-static hipError_t launch_wave1024x2_kind(const float *x, float *out, const float *table, int64_t frame_begin,
-                                         int64_t n_frames, float log_floor, hipStream_t stream, const Channels &ch)
-{
-    const int64_t chunks = (n_frames + 7) / 8;
-    const size_t lds = 0;                         // the kernel's LDS is static (three objects, see the kernel)
-    static thread_local int cached_grid = 0;      // per thread: plans of different threads are independent
-    if (cached_grid == 0)
-        cached_grid = persistent_grid(stft_wave1024x2_kernel<K>, lds);
-    const int64_t want = experiment_knob("AA_GRID_SET", cached_grid, 1, 1 << 16);
-    const dim3 grid(channel_grid(want, chunks, ch.n)), block(kWave1024Threads);
-    hipLaunchKernelGGL((stft_wave1024x2_kernel<K>), grid, block, lds, stream, x, out, table, frame_begin, n_frames,
-                       chunks, log_floor, ch.n, ch.in_stride, ch.out_stride);
-    return hipGetLastError();
-}
-
-hipError_t launch_wave1024x2(int out_kind, const float *x, float *out, const float *table, int64_t frame_begin,
-                             int64_t n_frames, float log_floor, hipStream_t stream, const Channels *channels)
-{
-    const Channels ch = channels ? *channels : Channels();
-    if (ch.n < 1 || (ch.n > 1 && ((ch.in_stride | ch.out_stride) & 3)))
-        return hipErrorInvalidValue;
-    if (n_frames <= 0)
-        return hipSuccess;
-    // LDS-DMA of 16-byte pieces and aligned nontemporal row stores
-    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) != 0)
-        return hipErrorInvalidValue;
-    switch (out_kind) {
-    case kMag:
-        return launch_wave1024x2_kind<kMag>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
-    case kPower:
-        return launch_wave1024x2_kind<kPower>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
-    case kLogPower:
-        return launch_wave1024x2_kind<kLogPower>(x, out, table, frame_begin, n_frames, log_floor, stream, ch);
-    default:
-        return hipErrorInvalidValue;
-    }
-}
-
-template <int K, int NS = 0>
 static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, const float *table,
                                        int64_t frame_begin, int64_t n_frames, int hop, int frames_per_wg,
                                        float log_floor, hipStream_t stream, const float *mel_par,
                                        const MelSched &sch, const Channels &ch)
 {
     const int64_t chunks = (n_frames + frames_per_wg - 1) / frames_per_wg;
-    constexpr int kMelKind = K == kLogMelR ? 2 : K == kLogMel ? 1 : 0;
-    // The tuner geometry (hop 512, four frames per chunk) stages through the ring with the DMA two
-    // chunks ahead (RING == 2): log-mel 96.4 -> 88.2 us, magnitudes 82.9 -> 80.1, complex rows 96.3 ->
-    // 91.7 with the samples coming from HBM (two inputs alternating).  The four-workgroup variant with
-    // streamed constants (RING == 1) loses to it everywhere (complex rows 96.4-100.5 us, magnitudes
-    // +3-6 %: the extra residents only queue for issue slots) and is only built with -DAA_RING_COMPLEX=1.  The mel
-    // variant with arithmetic weights keeps the two chunk buffers (its LDS has no room for the ring).
-    // AA_W2048_RING=0: experiments.
-#ifndef AA_RING_COMPLEX
-#define AA_RING_COMPLEX 2
-#endif
-    constexpr int kRingKind = K == kComplex ? AA_RING_COMPLEX : K == kLogMel ? 0 : 2;   // built for this output kind
+    constexpr int kMelKind = K == kLogMel ? 1 : 0;
+    // The tuner geometry (hop 512, four frames per chunk) stages through the ring with the DMA two chunks ahead
+    // (RING == 2; r2: magnitudes 82.9 -> 80.1 us, complex rows 96.3 -> 91.7 with the samples coming from HBM).  The
+    // fallback log-mel rows with arithmetic weights keep the two chunk buffers (their LDS has no room for the ring).
+    // AA_W2048_RING=0: experiment builds.
+    constexpr int kRingKind = K == kLogMel ? 0 : 2;   // built for this output kind
     int ring = hop == 512 && frames_per_wg == 4 ? kRingKind : 0;
     if (experiment_knob("AA_W2048_RING", 1, 0, 1) == 0)     // experiment builds: the two chunk buffers
         ring = 0;
-    size_t lds = ring ? wave2048_ring_lds_bytes(ring == 2 ? 30 : 22, kMelKind)
+    size_t lds = ring ? wave2048_ring_lds_bytes(30, kMelKind)
                       : wave2048_lds_bytes(frames_per_wg, hop, kMelKind != 0);
     // AA_LDS_PAD (experiment builds): fewer resident workgroups per CU; never past the 64 KiB a plan validated
     const size_t pad = (size_t)experiment_knob("AA_LDS_PAD", 0, 0, 65536);
@@ -4465,25 +3068,25 @@ static hipError_t launch_wave2048_kind(bool wide, const float *x, float *out, co
     static thread_local int cached_grid[2] = {0, 0};   // per thread: plans of different threads are independent
     static thread_local size_t cached_lds[2] = {0, 0};
     if (cached_grid[ri] == 0 || cached_lds[ri] != lds) {
-        cached_grid[ri] = ring ? persistent_grid(stft_wave2048_kernel<K, true, NS, kRingKind>, lds)
-                               : persistent_grid(stft_wave2048_kernel<K, true, NS, 0>, lds);
+        cached_grid[ri] = ring ? persistent_grid(stft_wave2048_kernel<K, true, kRingKind>, lds)
+                               : persistent_grid(stft_wave2048_kernel<K, true, 0>, lds);
         cached_lds[ri] = lds;
     }
     const dim3 grid(channel_grid(cached_grid[ri], chunks, ch.n)), block(kWave1024Threads);
     if (ring && wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, kRingKind>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, kRingKind>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
                            ch.out_stride);
     else if (ring)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, kRingKind>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, kRingKind>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
                            ch.out_stride);
     else if (wide)
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, NS, 0>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, true, 0>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
                            ch.out_stride);
     else
-        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, NS, 0>), grid, block, lds, stream, x, out, table,
+        hipLaunchKernelGGL((stft_wave2048_kernel<K, false, 0>), grid, block, lds, stream, x, out, table,
                            frame_begin, n_frames, hop, frames_per_wg, chunks, log_floor, mel_par, sch, ch.n, ch.in_stride,
                            ch.out_stride);
     return hipGetLastError();
@@ -4518,8 +3121,6 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
     const MelSched sch = sched ? *sched : MelSched();
     if (out_kind == kLogMel && (!mel_par || sch.n_groups < 1 || sch.n_groups > kMelMaxGroups))
         return hipErrorInvalidValue;
-    if (out_kind == kLogMelR && (!mel_par || sch.n_steps < 1 || sch.n_steps > kMelStreamMaxSteps))
-        return hipErrorInvalidValue;
     if (out_kind == kLogMelM) {
         if (!mel_par || hop != 512 || frames_per_wg != 4 || sch.n_steps < 1 || sch.n_steps > kMelMfmaSteps2048 ||
             sch.n_mels < 16 || sch.n_mels > kMelMaxMels || (sch.n_mels & 3) || (reinterpret_cast<uintptr_t>(out) & 15u))
@@ -4538,12 +3139,6 @@ hipError_t launch_wave2048(int out_kind, const float *x, float *out, const float
         return launch_wave2048_kind<kLogPower>(wide, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     case kLogMel:
         return launch_wave2048_kind<kLogMel>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
-    case kLogMelR:   // the instantiation with the fewest steps that holds the schedule
-        if (sch.n_steps <= 12)
-            return launch_wave2048_kind<kLogMelR, 12>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
-        if (sch.n_steps <= 14)
-            return launch_wave2048_kind<kLogMelR, 14>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
-        return launch_wave2048_kind<kLogMelR, 16>(false, x, out, table, frame_begin, n_frames, hop, frames_per_wg, log_floor, stream, mel_par, sch, ch);
     default:
         return hipErrorInvalidValue;
     }
@@ -4698,6 +3293,5 @@ hipError_t launch_generic_inverse(bool pow2, const float *spec, float *out, cons
 }
 
 #endif  // AA_TU_MFCC
-#endif  // AA_ABLATE
 
 }  // namespace aa

@@ -49,6 +49,7 @@ class Stft:
         self.n_fft, self.hop, self.output = int(n_fft), int(hop), output
         self.cols = int(self._lib.aa_stft_out_cols(self._plan))
         self.kernel = self._lib.aa_stft_kernel_name(self._plan).decode()
+        self.mel_path = self._lib.aa_stft_mel_path_name(self._plan).decode()
         self.device_index = _current_device_index()
 
     def close(self):

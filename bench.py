@@ -200,6 +200,40 @@ class GpuTimer:
         return e0.elapsed_time(e1) / steps, wall
 
 
+def sustained_leg(timer, step, kernel_ms, seconds=2.0):
+    """>= `seconds` of back-to-back headline launches between one pair of HIP events: the power-limited steady state
+    (the K-step figure above can still ride the boost clock: DESIGN.md section 5), long enough for an SMI sampler to see."""
+    n = max(int(seconds / (kernel_ms * 1e-3)) + 1, 100)
+    ms, wall = timer.time(step, n, 0)
+    return {"launches": n, "seconds": r4(wall), "ms_per_step": ms}
+
+
+def copy_ceiling(torch, dev, timer, n_in, n_out):
+    """What this box's memory system delivers for the launch's byte count with NO arithmetic: (i) a plain device copy of
+    (in + out) / 2 floats (reads as many bytes as it writes), (ii) the launch's own 1 : 2 read : write mix (every input
+    float written twice).  torch's elementwise kernels on the launch stream, HIP events over 50 runs after a ramp.
+    SURVEY.md section 8d: "report both nominal and measured-copy ceilings"."""
+    half = (n_in + n_out) // 2
+    src = torch.empty(half, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty(half, dtype=torch.float32, device=dev)
+    a = torch.empty(n_in, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty((2, n_in), dtype=torch.float32, device=dev)
+    with torch.cuda.stream(timer.stream):
+        def copy():
+            dst.copy_(src)
+
+        def mix():
+            b.copy_(a.unsqueeze(0).expand(2, n_in))
+
+        timer.ramp(copy, 0.1)
+        ms_copy, _ = timer.time(copy, 50, 5)
+        timer.ramp(mix, 0.1)
+        ms_mix, _ = timer.time(mix, 50, 5)
+    del src, dst, a, b
+    return {"copy_GBps": 2 * half * 4 / (ms_copy * 1e-3) / 1e9, "mix_1r2w_GBps": 3 * n_in * 4 / (ms_mix * 1e-3) / 1e9,
+            "how": "torch copy_ of (in + out) / 2 floats; torch broadcast copy of the input floats into 2 x as many"}
+
+
 def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     """The BASELINE configurations beside the headline, each timed like it (HIP events over
     `steps` launches after `warmup`), with algorithmic bytes per frame and the HBM fraction."""
@@ -235,12 +269,6 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     geometry("mag_2048_512", 2048, 512, "mag", 512 * 4 + 1025 * 4)
     geometry("mag_256_64", 256, 64, "mag", 64 * 4 + 129 * 4)
     geometry("complex_1024_256", 1024, 256, "complex", 256 * 4 + 513 * 8)
-    # the opt-in two-frames-per-wave kernel of the headline geometry (16 x 16 x 2), for the record
-    os.environ["AA_W1024_X2"] = "1"
-    try:
-        geometry("mag_1024_256_x2", N_FFT, HOP, "mag", BYTES_PER_FRAME)
-    finally:
-        del os.environ["AA_W1024_X2"]
 
     # configs[2]: 2048-pt + 128 log-mel on synthetic stereo (two channels, seeds 12345 / 54321)
     n_mels = 128
@@ -409,6 +437,9 @@ def run_single(args):
 
     achieved_gbs = BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = load_traffic()
+    sus = sustained_leg(timer, step, kernel_ms)
+    sus_gbs = BYTES_PER_FRAME * nf / (sus["ms_per_step"] * 1e-3) / 1e9
+    ceil = copy_ceiling(torch, dev, timer, xd.shape[0], nf * plan.cols)
     result = {
         "metric": "STFT frames/s (1024-pt, hop 256, 48 kHz f32)",
         "value": nf * args.steps / elapsed,
@@ -432,7 +463,15 @@ def run_single(args):
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_from_profile": traffic_src,
             "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": nf,
+            # measured on this box, in this run (not a target: the nominal peak above stays `peak`)
+            "copy_ceiling": {"copy_GBps": r4(ceil["copy_GBps"]), "mix_1r2w_GBps": r4(ceil["mix_1r2w_GBps"]),
+                             "frac_of_copy": r4(achieved_gbs / ceil["copy_GBps"]),
+                             "frac_of_mix": r4(achieved_gbs / ceil["mix_1r2w_GBps"]), "how": ceil["how"]},
         },
+        # >= 2 s of back-to-back launches of the same kernel between one pair of events
+        "sustained_ms_per_step": sus["ms_per_step"], "sustained_frac": sus_gbs / HBM_PEAK_GBS,
+        "sustained": {"launches": sus["launches"], "seconds": sus["seconds"],
+                      "frames_per_s": nf / (sus["ms_per_step"] * 1e-3)},
         "post_check_max_err": r4(post_err), "post_check_rows": int(len(ids)), "post_check_tol": TOL_VS_TRUTH,
     }
     ok = post_err <= TOL_VS_TRUTH

@@ -153,12 +153,22 @@ int aa_stft_plan_destroy(aa_stft_plan *plan);
 int64_t aa_stft_num_frames(const aa_stft_plan *plan, int64_t n_samples);
 /* floats per output row for the plan's output kind. */
 int32_t aa_stft_out_cols(const aa_stft_plan *plan);
-/* Name of the FFT kernel family the plan selected: "wave1024" (one wave per frame; its log-mel / MFCC plans run
- * stft_wave1024_mel_kernel), "wave1024x2" (opt-in, AA_W1024_X2=1 at plan creation: magnitude-type rows at hop 256 -
- * falls back to "wave1024"'s kernel for a call whose buffers are not 16-byte aligned), "wave2048", "wave512",
+/* Name of the FFT kernel family the plan selected: "wave1024", "wave2048" (one wave per frame), "wave512",
  * "wave256", "wave128" (several frames per wave), "wg_stockham" (one workgroup per frame: 4096 / 8192, and 1024 /
- * 2048 at hops that are not multiples of 4), "lds_stockham" (other powers of two), "dft" (even non-powers of two). */
+ * 2048 at hops that are not multiples of 4), "lds_stockham" (other powers of two), "dft" (even non-powers of two).
+ * The wave kernels stage 16-byte pieces: a call whose first sample is not 16-byte aligned runs on the generic
+ * kernel of the same length instead (same rows to rounding). */
 const char *aa_stft_kernel_name(const aa_stft_plan *plan);
+/* How an AA_OUT_LOGMEL / AA_OUT_MFCC plan reduces the power rows ("" for the other output kinds); it follows from
+ * the plan's parameters alone:
+ *   "mfma"         inside the wave kernel, the filterbank band-blocked on v_mfma_f32_4x4x1 (stft_wave1024_mel_kernel
+ *                  at 8 frames per chunk, stft_wave2048_mel_kernel at hop 512; n_mels % 4 == 0, 16-byte-aligned rows);
+ *   "mfma+dct"     MFCC: the same with the DCT-II fused behind it (n_fft 1024, n_mfcc <= 64) - one launch;
+ *   "gather"       inside the wave kernel on the VALU, weights rebuilt from the triangle edges (any band count / hop);
+ *   "gather+gemm"  MFCC: log-mel slab from "gather", then the DCT-II as an f32 MFMA GEMM;
+ *   "gemm"         power slab -> f32 MFMA filterbank GEMM (-> DCT GEMM): the generic FFT kernels, and any call whose
+ *                  first sample is not 16-byte aligned. */
+const char *aa_stft_mel_path_name(const aa_stft_plan *plan);
 
 /* Frames [frame_begin, frame_end) of the buffer `samples_dev[0 .. n_samples)`,
  * rows written from out_dev[0].  frame indices are relative to samples_dev[0]:

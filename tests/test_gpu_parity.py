@@ -218,51 +218,6 @@ def test_wave1024_power_and_logpower(aa, oracle_mod, torch_mod):
     assert np.max(np.abs(got_l - ref_l)[near]) < 1e-3
 
 
-def test_two_frames_per_wave_kernel_opt_in(aa, oracle_mod, torch_mod, monkeypatch):
-    """stft_wave1024x2_kernel (AA_W1024_X2=1 at plan creation; 512 = 16 x 16 x 2, two frames side by side in
-    the half-waves; not the default: DESIGN.md section 8) against the CPU oracle and the float64 truth:
-    ragged frame counts around the 8-frame chunk and the ring of 11 blocks, sub-ranges, power / log-power,
-    two channels in one launch, and the same rows as the default kernel to rounding."""
-    monkeypatch.setenv("AA_W1024_X2", "1")
-    n, hop = 1024, 256
-    plan = aa.Stft(n, hop, output="mag")
-    assert plan.kernel == "wave1024x2"
-    monkeypatch.delenv("AA_W1024_X2")
-    ref_plan = aa.Stft(n, hop, output="mag")
-    assert ref_plan.kernel == "wave1024"
-    w = oracle_mod.hann_window(n)
-    for n_frames in (1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 87, 88, 89, 1000, 4099):
-        rng = np.random.default_rng(n_frames)
-        L = n + (n_frames - 1) * hop + int(rng.integers(0, hop))
-        x = (0.5 * rng.standard_normal(L)).astype(np.float32)
-        xd = torch_mod.from_numpy(x).cuda()
-        buf = torch_mod.full((n_frames * 513 + 64,), float("nan"), device="cuda")
-        got = plan.execute_device(xd, 0, n_frames, out=buf[:n_frames * 513].view(n_frames, 513))
-        torch_mod.cuda.synchronize()
-        assert torch_mod.isnan(buf[n_frames * 513:]).all(), "wrote past the slab"
-        got = got.cpu().numpy()
-        assert nerr(got, oracle_mod.stft(x, n, hop, kind="mag").astype(np.float64)).max() < TOL_VS_ORACLE
-        assert nerr(got, np.abs(oracle_mod.truth.stft_complex(x, n, hop, w))).max() < TOL_VS_TRUTH
-        assert nerr(got, ref_plan(xd).cpu().numpy().astype(np.float64)).max() < 2e-6
-    x = aa.signals.synth_corpus(5, n + 999 * hop)
-    xd = torch_mod.from_numpy(x).cuda()
-    full = plan(xd).cpu().numpy()
-    for f0, f1 in ((1, 1000), (7, 13), (8, 9), (123, 999), (500, 501)):
-        assert np.array_equal(plan.execute_device(xd, f0, f1).cpu().numpy(), full[f0:f1])
-    monkeypatch.setenv("AA_W1024_X2", "1")
-    P = np.abs(oracle_mod.truth.stft_complex(x, n, hop, w)) ** 2
-    pw = aa.Stft(n, hop, output="power")
-    assert pw.kernel == "wave1024x2"
-    assert nerr(pw(xd).cpu().numpy(), P).max() < 2 * TOL_VS_TRUTH
-    lg = aa.Stft(n, hop, output="logpower")(xd).cpu().numpy()
-    assert nerr(10.0 ** (lg.astype(np.float64) / 10.0), np.maximum(P, 1e-10)).max() < 4 * TOL_VS_TRUTH
-    # two planar channels in one launch (aa_stft_execute_channels_device): rows equal to per-channel launches
-    y = aa.signals.synth_corpus(6, n + 999 * hop, seed=54321)
-    both = torch_mod.from_numpy(np.stack([x, y])).cuda()
-    rows = plan.execute_channels_device(both).cpu().numpy()
-    assert np.array_equal(rows[0], full) and np.array_equal(rows[1], plan(torch_mod.from_numpy(y).cuda()).cpu().numpy())
-
-
 def test_frame_subrange_and_misaligned_fallback(aa, oracle_mod, torch_mod):
     n, hop = 1024, 256
     rng = np.random.default_rng(9)
@@ -386,43 +341,65 @@ def test_logmel_two_channels(aa, oracle_mod, torch_mod, n, hop):
     assert np.max(np.abs(got[32760:] - L)[near]) < 1e-3
 
 
-@pytest.mark.parametrize("n,hop", [(2048, 512), (1024, 256)])
-@pytest.mark.parametrize("n_mels,fmin,fmax", [(128, 0.0, None), (80, 20.0, 8000.0), (40, 0.0, 12000.0), (100, 300.0, None), (17, 50.0, 3000.0)])
-def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, monkeypatch, n, hop, n_mels, fmin, fmax):
-    """The wave kernels reduce the power row to mel bands in LDS (triangular gather, weights from
-    the two edges of each triangle); AA_MEL_GEMM=1 selects the unfused power slab + MFMA
-    filterbank.  Both must match the float64 definition, for any band count / band edges."""
+def _unaligned(torch_mod, xd):
+    """The same samples 4 bytes past a 16-byte boundary: such a call cannot use the wave kernels (they stage 16-byte
+    pieces) and runs the generic FFT kernel - for mel plans the power slab + filterbank GEMM (+ DCT GEMM) path."""
+    buf = torch_mod.empty(xd.numel() + 1, dtype=xd.dtype, device=xd.device)
+    buf[1:].copy_(xd)
+    assert buf[1:].data_ptr() % 16 == 4
+    return buf[1:]
+
+
+@pytest.mark.parametrize("n,hop", [(2048, 512), (1024, 256), (1024, 512), (1024, 1000), (2048, 1000)])
+@pytest.mark.parametrize("n_mels,fmin,fmax", [(128, 0.0, None), (80, 20.0, 8000.0), (40, 0.0, 12000.0), (100, 300.0, None), (17, 50.0, 3000.0),
+                                               (126, 0.0, None)])
+def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, n, hop, n_mels, fmin, fmax):
+    """Three ways to the log-mel rows, each reached by the plan's parameters alone (aa_stft_mel_path_name): the
+    filterbank band-blocked on the matrix cores inside the wave kernel ("mfma": the shipped geometries, band counts
+    that are multiples of 4), the triangular gather on the VALU inside the wave kernel ("gather": other band
+    counts, other hops), and the unfused power slab + MFMA filterbank GEMM (any call whose samples are not 16-byte
+    aligned).  All must match the float64 definition, for any band count / band edges."""
     sr = 48000
     x = aa.signals.synth_corpus(9, n + 777 * hop)           # ragged last chunk included
     xd = torch_mod.from_numpy(x).cuda()
     kw = dict(output="logmel", sample_rate=sr, n_mels=n_mels, fmin=fmin, fmax=fmax or 0.0)
-    fused = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
-    monkeypatch.setenv("AA_MEL_GEMM", "1")
-    gemm = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
-    monkeypatch.delenv("AA_MEL_GEMM")
-    # table-driven weights when the schedule fits (1024: resident in registers, 2048: streamed from a
-    # per-lane table every frame); the other variant computes them from the triangle edges for every frame
-    monkeypatch.setenv("AA_MEL_NO_RESIDENT", "1")
-    alt = aa.Stft(n, hop, **kw)(xd).cpu().numpy()
-    monkeypatch.delenv("AA_MEL_NO_RESIDENT")
+    plan = aa.Stft(n, hop, **kw)
+    # (1024 / 512 still stages 8 frames per chunk and takes the contraction; at hop 1000 the 2048 kernel gathers and the
+    # 1024 kernel, with fewer than 8 frames per chunk, leaves the reduction to the GEMM)
+    want = "mfma" if hop != 1000 and n_mels % 4 == 0 else "gemm" if (n, hop) == (1024, 1000) else "gather"
+    assert plan.mel_path == want
+    fused = plan(xd).cpu().numpy()
+    gemm = plan(_unaligned(torch_mod, xd)).cpu().numpy()
     tr = oracle_mod.truth
     P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
     M = np.maximum(P @ tr.mel_filterbank(sr, n, n_mels, fmin, fmax).T, 1e-10)
     assert fused.shape == gemm.shape == M.shape == (778, n_mels)
-    for got in (fused, gemm, alt):
+    for got in (fused, gemm):
         assert nerr(10.0 ** (got.astype(np.float64) / 10.0), M).max() < 2e-5
     L = 10.0 * np.log10(M)
     near = L >= L.max(axis=1, keepdims=True) - 40.0
     assert np.max(np.abs(fused - gemm)[near]) < 1e-3
 
 
+def test_mel_path_names(aa):
+    """aa_stft_mel_path_name: the reduction a plan takes follows from its parameters (include/aa_stft.h)."""
+    mk = lambda n, hop, out, **kw: aa.Stft(n, hop, output=out, sample_rate=48000, **kw).mel_path
+    assert mk(1024, 256, "mag") == ""
+    assert mk(1024, 256, "logmel", n_mels=128) == "mfma" and mk(2048, 512, "logmel", n_mels=40) == "mfma"
+    assert mk(1024, 256, "logmel", n_mels=30) == "gather" and mk(2048, 500, "logmel", n_mels=128) == "gather"
+    assert mk(1024, 256, "mfcc", n_mels=128, n_mfcc=40) == "mfma+dct"
+    assert mk(1024, 256, "mfcc", n_mels=126, n_mfcc=33) == "gather+gemm"
+    assert mk(1024, 256, "mfcc", n_mels=128, n_mfcc=80) == "gather+gemm"
+    assert mk(2048, 512, "mfcc", n_mels=128, n_mfcc=40) == "gather+gemm"
+    assert mk(4096, 1024, "logmel", n_mels=128) == "gemm" and mk(512, 128, "mfcc", n_mels=40, n_mfcc=13) == "gemm"
+
+
 @pytest.mark.parametrize("sr,n_mels", [(16000, 64), (16000, 128), (22050, 80), (44100, 80), (44100, 128),
                                         (96000, 64), (96000, 128), (22050, 40), (8000, 24)])
 def test_streamed_mel_schedules_2048(aa, oracle_mod, torch_mod, sr, n_mels):
-    """The 2048 kernel streams the filter weights from a per-lane table when the schedule fits 16
-    steps of 4 bins (instantiations for 12 / 14 / 16 steps: the sample rates and band counts here
-    land on each of them) and falls back to weights rebuilt from the triangle edges otherwise
-    (40 bands at 22.05 kHz need 18 steps).  All against the float64 definition."""
+    """The 2048 kernel's band-blocked contraction takes up to seven 4-bin steps per block (the sample rates and band
+    counts here land on different step counts) and the plan falls back to the VALU gather when a filterbank does not
+    fit.  All against the float64 definition."""
     n, hop = 2048, 512
     x = aa.signals.synth_corpus(11, n + 333 * hop)          # ragged last chunk included
     got = aa.Stft(n, hop, output="logmel", sample_rate=sr, n_mels=n_mels)(torch_mod.from_numpy(x).cuda()).cpu().numpy()
@@ -1088,21 +1065,21 @@ def test_mag_edge_values(aa, torch_mod, n):
 
 
 # ------------------------------------------------------ fused MFCC (DCT on the matrix cores) --
-@pytest.mark.parametrize("n_mels,n_mfcc", [(128, 40), (128, 13), (128, 64), (80, 20), (40, 40), (64, 17), (126, 33), (65, 12)])
-def test_fused_mfcc_matches_truth_and_unfused_path(aa, oracle_mod, torch_mod, monkeypatch, n_mels, n_mfcc):
+@pytest.mark.parametrize("n_mels,n_mfcc", [(128, 40), (128, 13), (128, 64), (80, 20), (40, 40), (64, 17), (126, 33), (65, 12), (128, 80)])
+def test_fused_mfcc_matches_truth_and_unfused_path(aa, oracle_mod, torch_mod, n_mels, n_mfcc):
     """BASELINE configs[4] at 1024 / 256: the DCT-II runs inside the STFT kernel (log-mel rows of 16
     frames stay in LDS, v_mfma_f32_16x16x4_f32).  Every row of ragged sizes - one frame, a lone last
-    chunk, odd and even chunk counts - against the float64 definition and against the two-kernel path
-    (AA_MFCC_NO_FUSE=1: log-mel slab + GEMM)."""
+    chunk, odd and even chunk counts - against the float64 definition and against the unfused path (power slab +
+    filterbank GEMM + DCT GEMM: the same plan on samples that are not 16-byte aligned).  Band counts that are no
+    multiple of 4 and more than 64 coefficients take the log-mel slab + DCT GEMM path."""
     sr, n, hop = 48000, 1024, 256
     tr = oracle_mod.truth
     dct = tr.dct2_ortho(n_mfcc, n_mels)
     fb = tr.mel_filterbank(sr, n, n_mels)
     kw = dict(output="mfcc", sample_rate=sr, n_mels=n_mels, n_mfcc=n_mfcc)
     fused = aa.Stft(n, hop, **kw)
-    monkeypatch.setenv("AA_MFCC_NO_FUSE", "1")
-    plain = aa.Stft(n, hop, **kw)
-    monkeypatch.delenv("AA_MFCC_NO_FUSE")
+    assert fused.mel_path == ("mfma+dct" if n_mels % 4 == 0 and n_mfcc <= 64 else "gather+gemm")
+    plain = lambda xd: fused(_unaligned(torch_mod, xd))
     rng = np.random.default_rng(n_mels * 100 + n_mfcc)
     for nf in (1, 2, 7, 8, 9, 15, 16, 17, 24, 25, 1000, 4099):
         L = n + (nf - 1) * hop

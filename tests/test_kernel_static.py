@@ -52,8 +52,10 @@ def test_no_wave_kernel_spills_and_occupancy_as_planned(fresh):
         assert k["m0_other_uses"] == 0, (name, k)        # m0 belongs to the hand-issued LDS-DMA alone
         if name.startswith("stft_wave1024_kernel<") and name.split("<")[1][0] in "0123":
             assert waves_per_simd(k["vgprs"]) == 4, (name, k)        # four workgroups of four waves per CU
-        if name.startswith("stft_wave1024x2_kernel") or name.startswith("stft_wave2048_kernel"):
-            assert waves_per_simd(k["vgprs"]) >= 3, (name, k)
+        if name.startswith("stft_wave2048_kernel") or "_mel_kernel" in name:
+            assert waves_per_simd(k["vgprs"]) >= 3, (name, k)        # three workgroups per CU (the mel kinds: LDS and registers)
     # the bench kernel's counted wait leaves its five row stores (4 dwordx4 + 1 dwordx2 per frame pair) in flight
-    assert 5 in fresh["kernels"]["stft_wave1024_kernel<1, 0, true, false>"]["vmcnt_waits"]
-    assert 5 in fresh["kernels"]["stft_wave1024x2_kernel<1>"]["vmcnt_waits"]
+    assert 5 in fresh["kernels"]["stft_wave1024_kernel<1, true>"]["vmcnt_waits"]
+    # the band-blocked mel kernels (r4): log-mel 1024 / 2048 and the fused MFCC kernel are in the record
+    for name in ("stft_wave1024_mel_kernel<7>", "stft_wave1024_mel_kernel<8>", "stft_wave2048_mel_kernel<7>"):
+        assert name in fresh["kernels"], sorted(fresh["kernels"])

@@ -19,13 +19,12 @@ cases = [(1024, 256, "mag", {}), (1024, 256, "complex", {}), (1024, 256, "logmel
          (2048, 512, "mag", {}), (2048, 512, "complex", {}), (2048, 512, "logmel", dict(n_mels=128)),
          (2048, 512, "logmel", dict(n_mels=40)), (2048, 500, "power", {}),
          (256, 64, "mag", {}), (512, 128, "mag", {}), (128, 32, "complex", {}),
-         (1024, 256, "mag", dict(x2=1)), (1024, 256, "logpower", dict(x2=1))]      # x2: stft_wave1024x2_kernel (opt-in)
+         (1024, 256, "logmel", dict(n_mels=30)), (1024, 256, "mfcc", dict(n_mels=126, n_mfcc=33))]   # the VALU-gather kinds
 xs = [torch.from_numpy(aa.signals.synth_corpus(0, 14_400_000 + 4 * 997, seed=12345 + 11 * i)).cuda() for i in range(2)]
 for n, hop, kind, kw in cases:
     kw = dict(kw)
-    os.environ["AA_W1024_X2"] = "1" if kw.pop("x2", 0) else "0"
     plan = aa.Stft(n, hop, output=kind, **kw)
-    kw["kernel"] = plan.kernel
+    kw["kernel"] = plan.kernel + ("/" + plan.mel_path if plan.mel_path else "")
     nf = plan.num_frames(xs[0].shape[0])
     outs = [torch.empty((nf, plan.cols), dtype=torch.float32, device="cuda") for _ in range(2)]
     st = torch.cuda.current_stream().cuda_stream

@@ -13,7 +13,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "audio_analyzer_rs_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-strict-aliasing"]      # as csrc/Makefile
-WAVE = re.compile(r"stft_wave(1024x2|1024|2048|_small)_kernel")
+WAVE = re.compile(r"stft_wave(1024|2048|_small)(_mel)?_kernel")
 
 
 def compile_asm(out_s, src="aa_kernels.hip", extra=()):

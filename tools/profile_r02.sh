@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the AA_SMALL_PLAIN_MAP pass needs a library built with -DAA_EXPERIMENTS=1 since r4 - tools/build_variants.sh)
 # Runs on the GPU box (via gpurun): the round-2 evidence set of the bench kernel and the other
 # configurations.  rocprofv3 kernel trace (+stats) and, in SEPARATE passes without any tracing,
 # the PMC counters.  Raw output under gpurun_out/prof/r02/; tools/summarize_r02.py condenses it

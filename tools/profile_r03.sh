@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the AA_SMALL_PLAIN_MAP pass needs a library built with -DAA_EXPERIMENTS=1 since r4 - tools/build_variants.sh)
 # Runs on the GPU box (via gpurun): the round-3 evidence set of the bench kernel and the other
 # configurations.  rocprofv3 kernel trace (+stats) and, in SEPARATE passes without any tracing,
 # the PMC counters.  Raw output under gpurun_out/prof/r03/; tools/summarize_r03.py condenses it
