@@ -86,6 +86,9 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); this is also the export list the CPU test checks
 # against include/aa_stft.h.
+# aa_piece_fn (include/aa_stft.h): int (*)(void *user, int64_t frame_begin, int64_t frame_end, void *stream)
+PIECE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)
+
 SIGNATURES = {
     "aa_last_error": (ctypes.c_char_p, []),
     "aa_abi_version": (ctypes.c_int, []),
@@ -171,6 +174,20 @@ SIGNATURES = {
                                           ctypes.c_void_p]),
     "aa_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_shard_piece": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _i64p, _i64p]),
+    "aa_scatter_samples_piece": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "aa_gather_rows_piece": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_void_p]),
+    "aa_sharded_pipeline": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int32, PIECE_FN, ctypes.c_void_p, ctypes.c_void_p]),
+    "aa_stft_execute_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "aa_stream_create": (ctypes.c_int, [ctypes.POINTER(StftConfig), ctypes.c_int32, _vpp]),
     "aa_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_stream_push": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int32, _f32p, _i64p,

@@ -1150,6 +1150,39 @@ int aa_stft_execute_device(aa_stft_plan *p, const float *samples_dev, int64_t n_
     return execute_device_impl(p, samples_dev, n_samples, frame_begin, frame_end, out_dev, stream, nullptr);
 }
 
+namespace {
+struct ShardedCall {
+    aa_stft_plan *plan;
+    const float *local;
+    int64_t local_n;
+    float *rows;
+    int cols;
+};
+int sharded_piece(void *user, int64_t fb, int64_t fe, void *stream)
+{
+    const ShardedCall *c = static_cast<const ShardedCall *>(user);
+    return aa_stft_execute_device(c->plan, c->local, c->local_n, fb, fe, c->rows + fb * c->cols, stream);
+}
+}  // namespace
+
+int aa_stft_execute_sharded(aa_stft_plan *p, aa_comm *cin, aa_comm *cout, const float *full_dev, int64_t n_samples,
+                            int32_t root, float *local_dev, int64_t local_capacity, float *rows_dev, float *out_dev,
+                            int32_t n_pieces, void *stream)
+{
+    if (!p || !cin || !cout)
+        return fail(AA_ERR_ARG, "aa_stft_execute_sharded: NULL plan or communicator");
+    const int64_t total = aa_stft_num_frames(p, n_samples);
+    int64_t f0 = 0, f1 = 0, s0 = 0, s1 = 0;
+    int rc = aa_shard_frames(total, aa_comm_world(cin), aa_comm_rank(cin), &f0, &f1);
+    if (rc == AA_OK)
+        rc = aa_shard_samples(f0, f1, p->cfg.n_fft, p->cfg.hop, &s0, &s1);
+    if (rc != AA_OK)
+        return rc;
+    ShardedCall call{p, local_dev, s1 - s0, rows_dev, aa_stft_out_cols(p)};
+    return aa_sharded_pipeline(cin, cout, full_dev, n_samples, p->cfg.n_fft, p->cfg.hop, call.cols, root, local_dev,
+                               local_capacity, rows_dev, out_dev, n_pieces, sharded_piece, &call, stream);
+}
+
 int aa_stft_execute_channels_device(aa_stft_plan *p, const float *samples_dev, int64_t n_samples,
                                     int64_t channel_stride, int32_t n_channels, float *out_dev,
                                     int64_t out_channel_stride, void *stream)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #define fail(...) aa::abi_fail(__VA_ARGS__)
 
@@ -162,6 +163,26 @@ void samples_of(int64_t f0, int64_t f1, int n_fft, int hop, int64_t *s0, int64_t
     *s0 = f0 * (int64_t)hop;                                 // == aa_shard_samples
     *s1 = (f1 == f0) ? *s0 : (f1 - 1) * (int64_t)hop + n_fft;
 }
+// Piece k of P of the frame range [f0, f1) (== aa_shard_piece): the same floor rule as the ranks' partition.
+void piece_of(int64_t f0, int64_t f1, int P, int k, int64_t *p0, int64_t *p1)
+{
+    const int64_t n = f1 - f0;
+    *p0 = f0 + (int64_t)(((__int128)n * k) / P);
+    *p1 = f0 + (int64_t)(((__int128)n * (k + 1)) / P);
+}
+// The samples piece k ADDS to what pieces 0 .. k-1 already delivered of the range of [f0, f1): consecutive pieces
+// share n_fft - hop samples (as consecutive ranks do) and every sample travels once.  [*a, *b) in global sample
+// indices; the pieces tile [s0, s1) of samples_of(f0, f1) exactly.
+void piece_samples_of(int64_t f0, int64_t f1, int P, int k, int n_fft, int hop, int64_t *a, int64_t *b)
+{
+    auto end_of = [&](int kk) {            // one past the last sample pieces 0 .. kk need
+        int64_t q0, q1;
+        piece_of(f0, f1, P, kk, &q0, &q1);
+        return q1 > f0 ? (q1 - 1) * (int64_t)hop + n_fft : f0 * (int64_t)hop;
+    };
+    *a = k == 0 ? f0 * (int64_t)hop : end_of(k - 1);
+    *b = end_of(k);
+}
 
 }  // namespace
 
@@ -169,6 +190,10 @@ struct aa_comm {
     ncclComm_t comm = nullptr;
     int world = 0, rank = 0, device = 0;
     float *token = nullptr;            // 2 * world floats on the device (aa_comm_barrier)
+    // aa_sharded_pipeline: the stream this communicator's exchanges run on next to the caller's compute stream,
+    // and the events that order the three against each other (created on first use, reused by later calls)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;
 };
 
 extern "C" {
@@ -237,6 +262,10 @@ int aa_comm_destroy(aa_comm *c)
             rc = nccl_fail("ncclCommDestroy", r);
     }
     (void)hipFree(c->token);
+    for (hipEvent_t e : c->events)
+        (void)hipEventDestroy(e);
+    if (c->side)
+        (void)hipStreamDestroy(c->side);
     delete c;
     return rc;
 }
@@ -263,25 +292,37 @@ int aa_comm_barrier(aa_comm *c, void *stream)
     return AA_OK;
 }
 
-int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int32_t n_fft, int32_t hop,
-                       int32_t root, float *local_dev, int64_t local_capacity, void *stream)
+int aa_shard_piece(int64_t f0, int64_t f1, int32_t n_pieces, int32_t piece, int64_t *p0, int64_t *p1)
 {
-    if (!c || n_samples < 0 || n_fft <= 0 || hop <= 0 || root < 0 || root >= c->world || local_capacity < 0)
+    if (!p0 || !p1 || f0 < 0 || f1 < f0 || n_pieces <= 0 || piece < 0 || piece >= n_pieces)
+        return fail(AA_ERR_ARG, "aa_shard_piece: bad argument (frames %lld..%lld, piece %d of %d)", (long long)f0,
+                    (long long)f1, piece, n_pieces);
+    piece_of(f0, f1, n_pieces, piece, p0, p1);
+    return AA_OK;
+}
+
+int aa_scatter_samples_piece(aa_comm *c, const float *full_dev, int64_t n_samples, int32_t n_fft, int32_t hop,
+                             int32_t root, float *local_dev, int64_t local_capacity, int32_t n_pieces, int32_t piece,
+                             void *stream)
+{
+    if (!c || n_samples < 0 || n_fft <= 0 || hop <= 0 || root < 0 || root >= c->world || local_capacity < 0 ||
+        n_pieces <= 0 || piece < 0 || piece >= n_pieces)
         return fail(AA_ERR_ARG, "aa_scatter_samples: bad argument");
     if (c->rank == root && !full_dev && n_samples > 0)
         return fail(AA_ERR_ARG, "aa_scatter_samples: the root needs the whole buffer");
     COMM_DEVICE(c, "aa_scatter_samples");
     const int64_t total = n_samples < n_fft ? 0 : (n_samples - n_fft) / hop + 1;
-    int64_t f0, f1, s0, s1;
+    int64_t f0, f1, s0, s1, a, b;
     frames_of(total, c->world, c->rank, &f0, &f1);
     samples_of(f0, f1, n_fft, hop, &s0, &s1);
     if (s1 - s0 > local_capacity || (s1 > s0 && !local_dev))
         return fail(AA_ERR_LEN, "aa_scatter_samples: rank %d needs %lld samples, local buffer holds %lld",
                     c->rank, (long long)(s1 - s0), (long long)local_capacity);
+    piece_samples_of(f0, f1, n_pieces, piece, n_fft, hop, &a, &b);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (c->rank == root) {
-        if (s1 > s0 && local_dev != full_dev + s0) {
-            hipError_t e = hipMemcpyAsync(local_dev, full_dev + s0, sizeof(float) * (size_t)(s1 - s0),
+        if (b > a && local_dev + (a - s0) != full_dev + a) {
+            hipError_t e = hipMemcpyAsync(local_dev + (a - s0), full_dev + a, sizeof(float) * (size_t)(b - a),
                                           hipMemcpyDeviceToDevice, st);
             if (e != hipSuccess)
                 return fail(AA_ERR_HIP, "aa_scatter_samples: %s", hipGetErrorString(e));
@@ -293,31 +334,40 @@ int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int
                 continue;
             int64_t g0, g1, t0, t1;
             frames_of(total, c->world, r, &g0, &g1);
-            samples_of(g0, g1, n_fft, hop, &t0, &t1);
+            piece_samples_of(g0, g1, n_pieces, piece, n_fft, hop, &t0, &t1);
             if (t1 > t0)
                 NCCL_TRY(g_rccl.Send(full_dev + t0, (size_t)(t1 - t0), kNcclFloat32, r, c->comm, st));
         }
         NCCL_TRY(grp.end());
-    } else if (s1 > s0) {
-        NCCL_TRY(g_rccl.Recv(local_dev, (size_t)(s1 - s0), kNcclFloat32, root, c->comm, st));
+    } else if (b > a) {
+        NCCL_TRY(g_rccl.Recv(local_dev + (a - s0), (size_t)(b - a), kNcclFloat32, root, c->comm, st));
     }
     return AA_OK;
 }
 
-int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int32_t cols, int32_t root,
-                   float *out_dev, void *stream)
+int aa_scatter_samples(aa_comm *c, const float *full_dev, int64_t n_samples, int32_t n_fft, int32_t hop,
+                       int32_t root, float *local_dev, int64_t local_capacity, void *stream)
 {
-    if (!c || total_frames < 0 || cols <= 0 || root < -1 || root >= c->world)
+    return aa_scatter_samples_piece(c, full_dev, n_samples, n_fft, hop, root, local_dev, local_capacity, 1, 0, stream);
+}
+
+int aa_gather_rows_piece(aa_comm *c, const float *rows_dev, int64_t total_frames, int32_t cols, int32_t root,
+                         float *out_dev, int32_t n_pieces, int32_t piece, void *stream)
+{
+    if (!c || total_frames < 0 || cols <= 0 || root < -1 || root >= c->world || n_pieces <= 0 || piece < 0 ||
+        piece >= n_pieces)
         return fail(AA_ERR_ARG, "aa_gather_rows: bad argument");
     COMM_DEVICE(c, "aa_gather_rows");
-    int64_t f0, f1;
+    int64_t f0, f1, p0, p1;
     frames_of(total_frames, c->world, c->rank, &f0, &f1);
+    piece_of(f0, f1, n_pieces, piece, &p0, &p1);
     const bool receiver = root < 0 || root == c->rank;
     if ((f1 > f0 && !rows_dev) || (receiver && total_frames > 0 && !out_dev))
         return fail(AA_ERR_ARG, "aa_gather_rows: NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (receiver && f1 > f0 && rows_dev != out_dev + f0 * cols) {
-        hipError_t e = hipMemcpyAsync(out_dev + f0 * cols, rows_dev, sizeof(float) * (size_t)((f1 - f0) * cols),
+    const float *mine = rows_dev + (p0 - f0) * cols;           // rows_dev holds the rank's whole range
+    if (receiver && p1 > p0 && mine != out_dev + p0 * cols) {
+        hipError_t e = hipMemcpyAsync(out_dev + p0 * cols, mine, sizeof(float) * (size_t)((p1 - p0) * cols),
                                       hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess)
             return fail(AA_ERR_HIP, "aa_gather_rows: %s", hipGetErrorString(e));
@@ -329,17 +379,119 @@ int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int3
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank)
             continue;
-        if (f1 > f0 && (root < 0 || root == r))              // my block goes to r
-            NCCL_TRY(g_rccl.Send(rows_dev, (size_t)((f1 - f0) * cols), kNcclFloat32, r, c->comm, st));
-        if (receiver) {                                      // r's block comes to me
-            int64_t g0, g1;
+        if (p1 > p0 && (root < 0 || root == r))              // my piece goes to r
+            NCCL_TRY(g_rccl.Send(mine, (size_t)((p1 - p0) * cols), kNcclFloat32, r, c->comm, st));
+        if (receiver) {                                      // r's piece comes to me
+            int64_t g0, g1, q0, q1;
             frames_of(total_frames, c->world, r, &g0, &g1);
-            if (g1 > g0)
-                NCCL_TRY(g_rccl.Recv(out_dev + g0 * cols, (size_t)((g1 - g0) * cols), kNcclFloat32, r, c->comm, st));
+            piece_of(g0, g1, n_pieces, piece, &q0, &q1);
+            if (q1 > q0)
+                NCCL_TRY(g_rccl.Recv(out_dev + q0 * cols, (size_t)((q1 - q0) * cols), kNcclFloat32, r, c->comm, st));
         }
     }
     NCCL_TRY(grp.end());
     return AA_OK;
+}
+
+int aa_gather_rows(aa_comm *c, const float *rows_dev, int64_t total_frames, int32_t cols, int32_t root,
+                   float *out_dev, void *stream)
+{
+    return aa_gather_rows_piece(c, rows_dev, total_frames, cols, root, out_dev, 1, 0, stream);
+}
+
+// ---- scatter k + 1 || compute k || gather k - 1 ---------------------------------------------------------------
+namespace {
+#define HIP_TRY(expr, what)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(AA_ERR_HIP, what ": %s", hipGetErrorString(e_));                       \
+    } while (0)
+
+int side_stream(aa_comm *c)
+{
+    if (!c->side)
+        HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "aa_sharded_pipeline");
+    return AA_OK;
+}
+int event_pool(aa_comm *c, size_t n)
+{
+    while (c->events.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), "aa_sharded_pipeline");
+        c->events.push_back(e);
+    }
+    return AA_OK;
+}
+}  // namespace
+
+int aa_sharded_pipeline(aa_comm *cin, aa_comm *cout, const float *full_dev, int64_t n_samples, int32_t n_fft,
+                        int32_t hop, int32_t cols, int32_t root, float *local_dev, int64_t local_capacity,
+                        float *rows_dev, float *out_dev, int32_t n_pieces, aa_piece_fn compute, void *user,
+                        void *stream)
+{
+    if (!cin || !cout || !compute || n_pieces <= 0 || n_pieces > 1024 || cols <= 0 || root < 0 || root >= cin->world ||
+        n_samples < 0 || n_fft <= 0 || hop <= 0)
+        return fail(AA_ERR_ARG, "aa_sharded_pipeline: bad argument");
+    if (cin->world != cout->world || cin->rank != cout->rank || cin->device != cout->device)
+        return fail(AA_ERR_ARG, "aa_sharded_pipeline: the two communicators must describe the same rank (world %d/%d, "
+                    "rank %d/%d, device %d/%d)", cin->world, cout->world, cin->rank, cout->rank, cin->device, cout->device);
+    COMM_DEVICE(cin, "aa_sharded_pipeline");
+    const int64_t total = n_samples < n_fft ? 0 : (n_samples - n_fft) / hop + 1;
+    int64_t f0, f1;
+    frames_of(total, cin->world, cin->rank, &f0, &f1);
+    int rc = side_stream(cin);
+    if (rc == AA_OK && cout != cin)
+        rc = side_stream(cout);
+    const int P = n_pieces;
+    if (rc == AA_OK)
+        rc = event_pool(cin, (size_t)(2 * P + 2));
+    if (rc != AA_OK)
+        return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream), sin = cin->side, sout = cout->side;
+    hipEvent_t *ev = cin->events.data();        // [0] fork, [1 + k] samples of piece k landed, [1 + P + k] rows of piece k computed,
+                                                // [1 + 2 P] last gather issued
+    // fork: both exchange streams start behind whatever the caller queued on `stream` (the producer of full_dev)
+    HIP_TRY(hipEventRecord(ev[0], st), "aa_sharded_pipeline");
+    HIP_TRY(hipStreamWaitEvent(sin, ev[0], 0), "aa_sharded_pipeline");
+    if (sout != sin)
+        HIP_TRY(hipStreamWaitEvent(sout, ev[0], 0), "aa_sharded_pipeline");
+    auto scatter = [&](int k) -> int {
+        int r = aa_scatter_samples_piece(cin, full_dev, n_samples, n_fft, hop, root, local_dev, local_capacity, P, k, sin);
+        if (r != AA_OK)
+            return r;
+        HIP_TRY(hipEventRecord(ev[1 + k], sin), "aa_sharded_pipeline");
+        return AA_OK;
+    };
+    // The issue order is the same on every rank - S0, S1, [C0], G0, S2, [C1], G1, .. - which is what RCCL asks of
+    // operations on one communicator (cin == cout) and of the two directions of a pair of ranks.
+    rc = scatter(0);
+    for (int k = 0; k < P && rc == AA_OK; ++k) {
+        if (k + 1 < P)
+            rc = scatter(k + 1);
+        if (rc != AA_OK)
+            break;
+        int64_t p0, p1;
+        piece_of(f0, f1, P, k, &p0, &p1);
+        HIP_TRY(hipStreamWaitEvent(st, ev[1 + k], 0), "aa_sharded_pipeline");
+        if (p1 > p0) {
+            rc = compute(user, p0 - f0, p1 - f0, stream);          // frames relative to the rank's range, as local_dev / rows_dev are
+            if (rc != AA_OK)
+                break;
+        }
+        HIP_TRY(hipEventRecord(ev[1 + P + k], st), "aa_sharded_pipeline");
+        HIP_TRY(hipStreamWaitEvent(sout, ev[1 + P + k], 0), "aa_sharded_pipeline");
+        rc = aa_gather_rows_piece(cout, rows_dev, total, cols, root, out_dev, P, k, sout);
+    }
+    // join: `stream` continues behind the last gather (and, through it, behind everything the pipeline queued) -
+    // also on an error path, so that nothing the caller queues next overtakes what was already issued
+    (void)hipEventRecord(ev[1 + 2 * P], sout);
+    (void)hipStreamWaitEvent(st, ev[1 + 2 * P], 0);
+    if (sin != sout) {
+        (void)hipEventRecord(ev[0], sin);
+        (void)hipStreamWaitEvent(st, ev[0], 0);
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -32,6 +32,23 @@ def shard_samples(f0, f1, n_fft, hop):
     return s0.value, s1.value
 
 
+def shard_piece(f0, f1, n_pieces, piece):
+    """Frames of piece `piece` of `n_pieces` of the range [f0, f1) (aa_shard_piece: the floor rule once more)."""
+    lib = _lib.load()
+    p0, p1 = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(lib.aa_shard_piece(int(f0), int(f1), int(n_pieces), int(piece), ctypes.byref(p0), ctypes.byref(p1)))
+    return p0.value, p1.value
+
+
+def piece_samples(f0, f1, n_pieces, piece, n_fft, hop):
+    """Global sample range piece `piece` ADDS to what pieces 0 .. piece-1 of [f0, f1) delivered: consecutive pieces
+    share n_fft - hop samples and every sample travels once (csrc/aa_comm.cpp: piece_samples_of)."""
+    def end_of(k):
+        _, q1 = shard_piece(f0, f1, n_pieces, k)
+        return (q1 - 1) * hop + n_fft if q1 > f0 else f0 * hop
+    return (f0 * hop if piece == 0 else end_of(piece - 1)), end_of(piece)
+
+
 def num_frames(n_samples, n_fft, hop):
     return 0 if n_samples < n_fft else (n_samples - n_fft) // hop + 1
 
@@ -131,6 +148,87 @@ def gather_rows(rows, shard, dst=None, out=None):
     return torch.cat([b[:f1 - f0] for b, (f0, f1) in zip(blocks, ranges)], dim=0)
 
 
+def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, out=None, group_in=None, group_out=None):
+    """scatter -> compute -> gather of a whole job with the three legs overlapped, over torch.distributed: every
+    rank's frame range is cut into `n_pieces` pieces (shard_piece) and piece k + 1's samples travel while piece k
+    is transformed and piece k - 1's rows go back to `src`.
+
+      full     rank `src`: the whole sample buffer (1-D float32); ignored elsewhere
+      execute  execute(local, frame_begin, frame_end, rows): queue the transform of local frames [frame_begin,
+               frame_end) of `local` (the rank's sample range) into rows[frame_begin:frame_end]
+      out      rank `src`: optional [total_frames, cols] destination
+    Returns (local, rows, out): out is the dense slab on `src`, None elsewhere; on `src` local / rows are views
+    of full / out (nothing is copied).
+
+    The exchanges are posted asynchronously (batch_isend_irecv) and waited for only where their data is needed; on
+    the "nccl" backend a wait() orders the current stream behind the exchange, and an exchange posted after a
+    launch is ordered behind it, so compute k overlaps scatter k + 1 and gather k - 1 on the device.  Every rank
+    posts S0, S1, G0, S2, G1, .. in this order (one communicator serialises them in issue order; pass two groups
+    to let scatters and gathers run side by side)."""
+    import torch
+    import torch.distributed as dist
+
+    P = int(n_pieces)
+    dev = device if device is not None else (full.device if full is not None else "cpu")
+    root = shard.rank == src
+    ranges = shard.all_frame_ranges()
+    if root:
+        if out is None:
+            out = torch.empty((shard.total_frames, cols), dtype=torch.float32, device=dev)
+        local = full[shard.s0:shard.s1]
+        rows = out[shard.f0:shard.f1]
+    else:
+        local = torch.empty(shard.local_samples, dtype=torch.float32, device=dev)
+        rows = torch.empty((shard.local_frames, cols), dtype=torch.float32, device=dev)
+
+    def post(ops, group):
+        if not ops or shard.world == 1:
+            return []
+        batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
+        return dist.batch_isend_irecv(batch)
+
+    def scatter(k):
+        ops = []
+        if root:
+            for r, (g0, g1) in enumerate(ranges):
+                a, b = piece_samples(g0, g1, P, k, shard.n_fft, shard.hop)
+                if r != src and b > a:
+                    ops.append(("send", full[a:b], r))
+        else:
+            a, b = piece_samples(shard.f0, shard.f1, P, k, shard.n_fft, shard.hop)
+            if b > a:
+                ops.append(("recv", local[a - shard.s0:b - shard.s0], src))
+        return post(ops, group_in)
+
+    def gather(k):
+        ops = []
+        if root:
+            for r, (g0, g1) in enumerate(ranges):
+                q0, q1 = shard_piece(g0, g1, P, k)
+                if r != src and q1 > q0:
+                    ops.append(("recv", out[q0:q1], r))
+        else:
+            q0, q1 = shard_piece(shard.f0, shard.f1, P, k)
+            if q1 > q0:
+                ops.append(("send", rows[q0 - shard.f0:q1 - shard.f0], src))
+        return post(ops, group_out)
+
+    pending = {0: scatter(0)}
+    tail = []
+    for k in range(P):
+        if k + 1 < P:
+            pending[k + 1] = scatter(k + 1)
+        for req in pending.pop(k):
+            req.wait()
+        q0, q1 = shard_piece(shard.f0, shard.f1, P, k)
+        if q1 > q0:
+            execute(local, q0 - shard.f0, q1 - shard.f0, rows)
+        tail += gather(k)
+    for req in tail:
+        req.wait()
+    return local, rows, (out if root else None)
+
+
 def gather_samples(local, shard, dst=0):
     """Inverse of scatter_samples: rank `dst` assembles the whole buffer from every rank's
     [s0, s1) range (the n_fft-hop halos overlap; each rank contributes only its new samples)."""
@@ -219,6 +317,35 @@ class Comm:
             self._comm, full.data_ptr() if self.rank == root else None, int(n_samples), int(n_fft), int(hop),
             int(root), local.data_ptr() if local.numel() else None, local.numel(), self._stream(local, stream)))
         return local
+
+    def execute_sharded(self, plan, full, n_samples, root=0, n_pieces=8, comm_out=None, out=None, stream=None,
+                        alias=True):
+        """aa_stft_execute_sharded: rank `root`'s samples in, the dense [total_frames, cols] slab on `root` out, with
+        scatter k + 1 || compute k || gather k - 1 (pieces of every rank's range).  `comm_out`: a second communicator
+        for the gathers (they then run next to the scatters instead of taking turns with them).  Stream-ordered on
+        `stream`; returns (local, rows, out) - out None off the root; on the root local / rows are views of full /
+        out (alias=False: buffers of their own, filled by device copies on the exchange streams)."""
+        import torch
+
+        shard = ShardPlan(n_samples, plan.n_fft, plan.hop, self.world, self.rank)
+        cols = plan.cols
+        if self.rank == root:
+            if not (full.is_cuda and full.dtype == torch.float32 and full.is_contiguous() and full.numel() == n_samples):
+                raise _lib.AaError(_lib.AA_ERR_ARG, "full must be a contiguous CUDA float32 tensor of n_samples")
+            if out is None:
+                out = torch.empty((shard.total_frames, cols), dtype=torch.float32, device=full.device)
+            local, rows = full[shard.s0:shard.s1], out[shard.f0:shard.f1]
+            if not alias:
+                local, rows = torch.empty_like(local), torch.empty_like(rows)
+        else:
+            local = torch.empty(shard.local_samples, dtype=torch.float32, device="cuda")
+            rows = torch.empty((shard.local_frames, cols), dtype=torch.float32, device="cuda")
+            out = None
+        ptr = lambda t: t.data_ptr() if t is not None and t.numel() else None
+        _lib.check(self._lib.aa_stft_execute_sharded(
+            plan._plan, self._comm, (comm_out or self)._comm, ptr(full) if self.rank == root else None, int(n_samples),
+            int(root), ptr(local), local.numel(), ptr(rows), ptr(out), int(n_pieces), self._stream(rows, stream)))
+        return local, rows, out
 
     def gather_rows(self, rows, total_frames, root=0, out=None, stream=None):
         """rows: this rank's CUDA float32 [local_frames, cols].  Rank `root` (every rank for

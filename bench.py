@@ -547,11 +547,19 @@ class HipCompute:
         if nf > 0:
             self.plan.execute_device(xd, 0, nf, out=out, stream=self.stream.cuda_stream)
 
+    def execute_range(self, xd, fb, fe, rows):
+        """frames [fb, fe) of the rank's range into their rows (one piece of the overlapped end-to-end leg)"""
+        if fe > fb:
+            self.plan.execute_device(xd, fb, fe, out=rows[fb:fe], stream=self.stream.cuda_stream)
+
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
 
     def events(self):
         return (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+
+
+E2E_PIECES = 8        # pieces per rank of the overlapped end-to-end leg (scatter k + 1 || compute k || gather k - 1)
 
 
 def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passes=3, ramp_s=0.25, ctx=None):
@@ -626,15 +634,36 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
     e2e = np.median(np.array(phases), axis=0)
 
     # ---- post-check on rank 0: gathered rows (every rank's block) against the truth --------------
-    post_err = None
-    if rank == 0:
+    def post_check(slab):
         ids = pick_rows(shard.total_frames, 64)
         for f0, f1 in shard.all_frame_ranges():                    # both edges of every shard
             ids = np.union1d(ids, [f0, max(f0, f1 - 1)])
-        ids = ids[ids < shard.total_frames]
-        full_np = full.cpu().numpy()
-        post_err = check_rows(full_np, rows_root[torch.from_numpy(ids).to(rows_root.device)].cpu().numpy(),
-                              ids, N_FFT, HOP, "mag")
+        for r, (f0, f1) in enumerate(shard.all_frame_ranges()):    # and both edges of every piece of the overlapped leg
+            for k in range(E2E_PIECES):
+                p0, p1 = aa.shard_piece(f0, f1, E2E_PIECES, k)
+                ids = np.union1d(ids, [p0, max(p0, p1 - 1)])
+        ids = ids[ids < shard.total_frames].astype(np.int64)
+        return check_rows(full.cpu().numpy(), slab[torch.from_numpy(ids).to(slab.device)].cpu().numpy(), ids, N_FFT, HOP, "mag")
+
+    post_err = post_check(rows_root) if rank == 0 else None
+
+    # ---- (iii) the same job with the three legs overlapped: every rank's range in E2E_PIECES pieces, piece k + 1's
+    # samples on their way while piece k is transformed and piece k - 1's rows travel back (aa.overlapped_e2e) ----
+    if rank == 0:
+        rows_root.fill_(float("nan"))
+    over = []
+    for p in range(e2e_passes + 1):
+        dist.barrier()
+        comp.sync()
+        ta = time.perf_counter()
+        aa.overlapped_e2e(full, shard, comp.execute_range, comp.cols, n_pieces=E2E_PIECES, src=0, device=out.device,
+                          out=rows_root)
+        comp.sync()
+        tb = time.perf_counter()
+        if p:
+            over.append(max_over_ranks(tb - ta))
+    overlapped = float(np.median(over))
+    post_err_overlapped = post_check(rows_root) if rank == 0 else None
     if ctx is not None:
         ctx.update(shard=shard, full=full, out=out, rows_root=rows_root, nf=nf)
     if rank != 0:
@@ -674,10 +703,17 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
             "what": "rank 0 scatters sample ranges (grouped send/recv), every rank computes, rows "
                     "gathered unpadded to rank 0; median of %d passes, max over ranks" % e2e_passes,
             "scatter_ms": r4(e2e[0] * 1e3), "compute_ms": r4(e2e[1] * 1e3), "gather_ms": r4(e2e[2] * 1e3),
-            "total_ms": r4(e2e[3] * 1e3), "frames_per_s": r4(total_frames / e2e[3]),
+            "serial_total_ms": r4(e2e[3] * 1e3), "serial_frames_per_s": r4(total_frames / e2e[3]),
             "gather_GBps": r4(total_frames * comp.cols * 4 * (world - 1) / world / e2e[2] / 1e9),
+            # the overlapped form of the same job: scatter k + 1 || compute k || gather k - 1
+            "total_ms": r4(overlapped * 1e3), "frames_per_s": r4(total_frames / overlapped),
+            "overlap": {"pieces_per_rank": E2E_PIECES, "total_ms": r4(overlapped * 1e3),
+                        "speedup_vs_serial": r4(e2e[3] / overlapped),
+                        "post_check_max_err": post_err_overlapped,
+                        "how": "aa.overlapped_e2e: batch_isend_irecv per piece, waited for where the data is needed"},
         },
-        "post_check_max_err": post_err, "post_check_tol": TOL_VS_TRUTH,
+        "post_check_max_err": post_err if post_err_overlapped is None else max(post_err, post_err_overlapped),
+        "post_check_tol": TOL_VS_TRUTH,
     }
 
 
@@ -780,18 +816,49 @@ def cabi_leg(dist, comp, world, rank, total_samples, ctx, box, passes=3):
         t = torch.tensor(np.median(np.array(times), axis=0), dtype=torch.float64, device=comp.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e = t.cpu().numpy()
-        err = None
-        if rank == 0:
+
+        def post_check():
             ids = pick_rows(shard.total_frames, 64, seed=5)
             for f0, f1 in shard.all_frame_ranges():
                 ids = np.union1d(ids, [f0, max(f0, f1 - 1)])
-            ids = ids[ids < shard.total_frames]
-            err = check_rows(full.cpu().numpy(), rows_root[torch.from_numpy(ids).to(comp.dev)].cpu().numpy(),
-                             ids, N_FFT, HOP, "mag")
+                for k in range(E2E_PIECES):
+                    p0, p1 = aa.shard_piece(f0, f1, E2E_PIECES, k)
+                    ids = np.union1d(ids, [p0, max(p0, p1 - 1)])
+            ids = ids[ids < shard.total_frames].astype(np.int64)
+            return check_rows(full.cpu().numpy(), rows_root[torch.from_numpy(ids).to(comp.dev)].cpu().numpy(),
+                              ids, N_FFT, HOP, "mag")
+
+        err = post_check() if rank == 0 else None
+        # the overlapped form: aa_stft_execute_sharded, gathers on a communicator of their own
+        uid2 = [aa.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid2, src=0)
+        comm_out = aa.Comm(uid2[0], world, rank)
+        if rank == 0:
+            rows_root.fill_(float("nan"))
+        over = []
+        for p in range(passes + 1):
+            comm.barrier(st)
+            ta = time.perf_counter()
+            comm.execute_sharded(comp.plan, full, total_samples, root=0, n_pieces=E2E_PIECES, comm_out=comm_out,
+                                 out=rows_root, stream=st)
+            comp.sync()
+            tb = time.perf_counter()
+            if p:
+                over.append(tb - ta)
+        comm.barrier(st)
+        t = torch.tensor([float(np.median(over))], dtype=torch.float64, device=comp.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ov = float(t.item())
+        err_over = post_check() if rank == 0 else None
+        comm_out.close()
         comm.close()
         box["result"] = {"backend": aa.Comm.backend(), "scatter_ms": r4(e[0] * 1e3), "compute_ms": r4(e[1] * 1e3),
-                         "gather_ms": r4(e[2] * 1e3), "total_ms": r4(e[3] * 1e3),
-                         "frames_per_s": r4(shard.total_frames / e[3]), "post_check_max_err": err}
+                         "gather_ms": r4(e[2] * 1e3), "serial_total_ms": r4(e[3] * 1e3),
+                         "total_ms": r4(ov * 1e3), "frames_per_s": r4(shard.total_frames / ov),
+                         "overlap": {"pieces_per_rank": E2E_PIECES, "speedup_vs_serial": r4(e[3] / ov),
+                                     "post_check_max_err": err_over,
+                                     "how": "aa_stft_execute_sharded: three streams, scatters and gathers on two communicators"},
+                         "post_check_max_err": err}
     except Exception as ex:                                  # noqa: BLE001 (reported, never fatal)
         box["error"] = f"{type(ex).__name__}: {ex}"
 
@@ -810,6 +877,11 @@ class RehearsalCompute(HipCompute):
         if nf > 0:
             xd = x_host.to(self.dev)
             out.copy_(self.plan.execute_device(xd, 0, nf, stream=self.stream.cuda_stream).cpu())
+
+    def execute_range(self, x_host, fb, fe, rows):
+        if fe > fb:
+            xd = x_host[fb * self.plan.hop:(fe - 1) * self.plan.hop + self.plan.n_fft].to(self.dev)
+            rows[fb:fe].copy_(self.plan.execute_device(xd, 0, fe - fb, stream=self.stream.cuda_stream).cpu())
 
     def events(self):
         return None

@@ -461,6 +461,42 @@ int aa_scatter_samples(aa_comm *comm, const float *full_dev, int64_t n_samples, 
 int aa_gather_rows(aa_comm *comm, const float *rows_dev, int64_t total_frames, int32_t cols,
                    int32_t root, float *out_dev, void *stream);
 
+/* The same two exchanges cut into n_pieces pieces per rank, so that a host can overlap them with the compute:
+ * piece k of the frame range [f0, f1) is [f0 + floor(k n / P), f0 + floor((k + 1) n / P)), n = f1 - f0 (the floor
+ * rule of aa_shard_frames once more; pieces of short ranges may be empty).  Pure integer. */
+int aa_shard_piece(int64_t f0, int64_t f1, int32_t n_pieces, int32_t piece, int64_t *p0, int64_t *p1);
+/* Piece `piece` of aa_scatter_samples: the samples that piece ADDS to what the earlier pieces delivered (consecutive
+ * pieces share n_fft - hop samples; every sample travels once), written at their place in local_dev - which holds
+ * the rank's WHOLE range, as for aa_scatter_samples.  Pieces must be issued in order, the same on every rank. */
+int aa_scatter_samples_piece(aa_comm *comm, const float *full_dev, int64_t n_samples, int32_t n_fft, int32_t hop,
+                             int32_t root, float *local_dev, int64_t local_capacity, int32_t n_pieces,
+                             int32_t piece, void *stream);
+/* Piece `piece` of aa_gather_rows: rows_dev is the rank's WHOLE [f1 - f0][cols] buffer, the piece's rows are taken
+ * from their place in it and land at their global rows of out_dev. */
+int aa_gather_rows_piece(aa_comm *comm, const float *rows_dev, int64_t total_frames, int32_t cols, int32_t root,
+                         float *out_dev, int32_t n_pieces, int32_t piece, void *stream);
+
+/* End to end on rank `root`'s buffer with the three legs overlapped: scatter of piece k + 1 || compute of piece k ||
+ * gather of piece k - 1.  The exchanges run on a stream owned by their communicator (comm_in: scatter, comm_out:
+ * gather; pass the same communicator twice and the two kinds of exchange take turns on it, pass two and they run
+ * side by side), the compute on `stream`; events order piece k's compute behind its samples and its gather behind
+ * its rows.  For the caller the whole call is stream-ordered on `stream`: it starts behind what was queued there
+ * and `stream` continues behind the last gather.  `compute(user, frame_begin, frame_end, stream)` must queue the
+ * transform of local frames [frame_begin, frame_end) - relative to the rank's range, as local_dev and rows_dev are
+ * - on `stream` and return AA_OK; it is called once per non-empty piece, in order.  One pipeline at a time per
+ * communicator.  Every rank issues S0, S1, G0, S2, G1, ... in this order (what RCCL requires of one communicator). */
+typedef int (*aa_piece_fn)(void *user, int64_t frame_begin, int64_t frame_end, void *stream);
+int aa_sharded_pipeline(aa_comm *comm_in, aa_comm *comm_out, const float *full_dev, int64_t n_samples,
+                        int32_t n_fft, int32_t hop, int32_t cols, int32_t root, float *local_dev,
+                        int64_t local_capacity, float *rows_dev, float *out_dev, int32_t n_pieces,
+                        aa_piece_fn compute, void *user, void *stream);
+/* aa_sharded_pipeline with aa_stft_execute_device of `plan` as the compute: rank `root`'s samples in, the dense
+ * [total_frames][cols] slab on `root` out.  local_dev: the rank's sample range (capacity in floats), rows_dev its
+ * [f1 - f0][cols] rows; on the root local_dev may be full_dev + s0 and rows_dev its slice of out_dev (no copies). */
+int aa_stft_execute_sharded(aa_stft_plan *plan, aa_comm *comm_in, aa_comm *comm_out, const float *full_dev,
+                            int64_t n_samples, int32_t root, float *local_dev, int64_t local_capacity,
+                            float *rows_dev, float *out_dev, int32_t n_pieces, void *stream);
+
 /* ---- streaming front end (ring-buffer ingest of stft.rs:198-201, 240-266) -- */
 typedef struct aa_stream aa_stream;
 

@@ -19,7 +19,7 @@ struct ncclComm { int world, rank; };
 typedef struct ncclComm *ncclComm_t;
 
 enum { kMaxLog = 1 << 16, kMaxRanks = 64, kMaxPending = 4096 };
-typedef struct { int op, rank, peer, in_group, device; uintptr_t ptr; size_t count; } LogEntry;   /* op 0 = send, 1 = recv */
+typedef struct { int op, rank, peer, in_group, device; uintptr_t ptr; size_t count; uintptr_t stream; } LogEntry;   /* op 0 = send, 1 = recv */
 static LogEntry g_log[kMaxLog];
 static int g_log_n, g_errors, g_group_depth, g_next_id = 1, g_group_open_calls, g_group_close_calls;
 typedef struct { void *ptr; size_t count; } Pending;
@@ -54,7 +54,7 @@ static void match(int src, int dst)
     }
 }
 
-static void log_op(int op, int rank, int peer, const void *ptr, size_t count)
+static void log_op(int op, int rank, int peer, const void *ptr, size_t count, void *stream)
 {
     typedef int (*getdev_fn)(int *);
     static getdev_fn getdev;
@@ -64,7 +64,7 @@ static void log_op(int op, int rank, int peer, const void *ptr, size_t count)
     if (getdev)
         (void)getdev(&dev);                  /* the device that is current while the call is made */
     if (g_log_n < kMaxLog) {
-        LogEntry e = {op, rank, peer, g_group_depth > 0, dev, (uintptr_t)ptr, count};
+        LogEntry e = {op, rank, peer, g_group_depth > 0, dev, (uintptr_t)ptr, count, (uintptr_t)stream};
         g_log[g_log_n++] = e;
     }
 }
@@ -109,12 +109,11 @@ int ncclGroupEnd(void)
 }
 int ncclSend(const void *buf, size_t count, int dtype, int peer, ncclComm_t comm, void *stream)
 {
-    (void)stream;
     if (dtype != 7 || peer < 0 || peer >= comm->world || g_send_n[comm->rank][peer] >= 64) {
         ++g_errors;
         return 4;
     }
-    log_op(0, comm->rank, peer, buf, count);
+    log_op(0, comm->rank, peer, buf, count, stream);
     Pending p = {(void *)buf, count};
     g_send[comm->rank][peer][g_send_n[comm->rank][peer]++] = p;
     match(comm->rank, peer);
@@ -122,12 +121,11 @@ int ncclSend(const void *buf, size_t count, int dtype, int peer, ncclComm_t comm
 }
 int ncclRecv(void *buf, size_t count, int dtype, int peer, ncclComm_t comm, void *stream)
 {
-    (void)stream;
     if (dtype != 7 || peer < 0 || peer >= comm->world || g_recv_n[peer][comm->rank] >= 64) {
         ++g_errors;
         return 4;
     }
-    log_op(1, comm->rank, peer, buf, count);
+    log_op(1, comm->rank, peer, buf, count, stream);
     Pending p = {buf, count};
     g_recv[peer][comm->rank][g_recv_n[peer][comm->rank]++] = p;
     match(peer, comm->rank);
@@ -149,6 +147,7 @@ int aa_stub_log_get(int i, int *op, int *rank, int *peer, int *in_group, int *de
     *ptr = g_log[i].ptr; *count = g_log[i].count;
     return 0;
 }
+size_t aa_stub_log_stream(int i) { return i < 0 || i >= g_log_n ? 0 : (size_t)g_log[i].stream; }
 int aa_stub_pending(void)
 {
     int n = 0;

@@ -47,6 +47,17 @@ lib.aa_gather_rows.argtypes = [vp, vp, i64, i32, i32, vp, vp]
 lib.aa_shard_frames.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
 lib.aa_shard_samples.argtypes = [i64, i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
 stub.aa_stub_log_get.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 5 + [ctypes.POINTER(ctypes.c_size_t)] * 2
+stub.aa_stub_log_stream.argtypes = [ctypes.c_int]
+stub.aa_stub_log_stream.restype = ctypes.c_size_t
+PIECE_FN = ctypes.CFUNCTYPE(ctypes.c_int, vp, i64, i64, vp)
+lib.aa_shard_piece.argtypes = [i64, i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+lib.aa_scatter_samples_piece.argtypes = [vp, vp, i64, i32, i32, i32, vp, i64, i32, i32, vp]
+lib.aa_gather_rows_piece.argtypes = [vp, vp, i64, i32, i32, vp, i32, i32, vp]
+lib.aa_sharded_pipeline.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, vp, i32, PIECE_FN, vp, vp]
+hip.hipDeviceSynchronize.argtypes = []
+if HOST_HIP:
+    hip.aa_hip_host_sync_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.POINTER(ctypes.c_size_t)]
 
 
 def ok(rc):
@@ -96,8 +107,33 @@ def log():
         p, c = ctypes.c_size_t(), ctypes.c_size_t()
         assert stub.aa_stub_log_get(i, *[ctypes.byref(x) for x in v], ctypes.byref(p), ctypes.byref(c)) == 0
         out.append(dict(op="send" if v[0].value == 0 else "recv", rank=v[1].value, peer=v[2].value,
-                        in_group=v[3].value, device=v[4].value, ptr=p.value, count=c.value))
+                        in_group=v[3].value, device=v[4].value, ptr=p.value, count=c.value,
+                        stream=stub.aa_stub_log_stream(i)))
     return out
+
+
+def sync_log():
+    """(kind, stream, event) of every hipEventRecord ("rec") / hipStreamWaitEvent ("wait") so far (host stand-in only)"""
+    out = []
+    for i in range(hip.aa_hip_host_sync_count()):
+        k, st, ev = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.aa_hip_host_sync_get(i, ctypes.byref(k), ctypes.byref(st), ctypes.byref(ev)) == 0
+        out.append(("rec" if k.value == 0 else "wait", st.value, ev.value))
+    return out
+
+
+def shard_piece(f0, f1, P, k):
+    p0, p1 = i64(), i64()
+    ok(lib.aa_shard_piece(f0, f1, P, k, ctypes.byref(p0), ctypes.byref(p1)))
+    return p0.value, p1.value
+
+
+def piece_samples(f0, f1, P, k, n, hop):
+    """the samples piece k adds to pieces 0 .. k-1 (every sample travels once)"""
+    def end_of(kk):
+        q1 = shard_piece(f0, f1, P, kk)[1]
+        return (q1 - 1) * hop + n if q1 > f0 else f0 * hop
+    return (f0 * hop if k == 0 else end_of(k - 1)), end_of(k)
 
 
 def quiet():
@@ -214,10 +250,177 @@ for world in (2, 3, 8):
                 for b in rows + [o for o in outs if o is not None]:
                     b.free()
                 checked += 1
+    # ---- the exchanges in pieces, and the overlapped pipeline (scatter k + 1 || compute k || gather k - 1) ----
+    comms2 = []
+    for r in range(world):
+        if HOST_HIP:
+            assert hip.hipSetDevice(r) == 0
+        c = vp()
+        ok(lib.aa_comm_create(uid, world, r, ctypes.byref(c)))
+        comms2.append(c)
+    if HOST_HIP:
+        assert hip.hipSetDevice(0) == 0
+    cols = 7
+    for total_frames, P, root in ((1000 + 37 * world + 5, 8, 0), (1000 + 37 * world + 5, 5, world - 1), (world + 1, 8, 0),
+                                  (world - 1, 3, world - 1), (0, 4, 0), (997, 1, 0)):
+        n_samples = 0 if total_frames == 0 else N + (total_frames - 1) * HOP + 17
+        x = np.random.default_rng(world * 77 + total_frames + P).standard_normal(n_samples).astype(np.float32)
+        frames = [shard_frames(total_frames, world, r) for r in range(world)]
+        ranges = [shard_samples(f0, f1, N, HOP) for f0, f1 in frames]
+        order = [root] + [r for r in range(world) if r != root]      # the root's sends first: a matched pair is carried
+                                                                     # out when its second half is posted
+        # (A) scatter in pieces: every sample once, at its place in the rank's buffer
+        stub.aa_stub_reset()
+        full = Dev(n_samples, x)
+        local = [Dev(s1 - s0 + 3) for s0, s1 in ranges]
+        for k in range(P):
+            for r in order:
+                ok(lib.aa_scatter_samples_piece(comms[r], full.ptr if r == root else None, n_samples, N, HOP, root,
+                                                local[r].ptr, local[r].n, P, k, None))
+        L = log()
+        quiet(); pairs_up(L)
+        for r, (s0, s1) in enumerate(ranges):
+            got = local[r].get()
+            assert np.array_equal(got[:s1 - s0], x[s0:s1]) and np.isnan(got[s1 - s0:]).all(), (world, root, r, P)
+        want_sends = [(r, *piece_samples(*frames[r], P, k, N, HOP)) for k in range(P) for r in range(world) if r != root]
+        want_sends = [(r, a, b) for r, a, b in want_sends if b > a]
+        assert [(e["peer"], (e["ptr"] - full.ptr) // 4, (e["ptr"] - full.ptr) // 4 + e["count"]) for e in L if e["op"] == "send"] == want_sends
+        assert [(e["rank"], (e["ptr"] - local[e["rank"]].ptr) // 4 + ranges[e["rank"]][0],
+                 (e["ptr"] - local[e["rank"]].ptr) // 4 + ranges[e["rank"]][0] + e["count"]) for e in L if e["op"] == "recv"] == want_sends
+        for r in range(world):                                       # per rank the pieces add up to its range, nothing twice
+            assert sum(b - a for rr, a, b in want_sends if rr == r) == (ranges[r][1] - ranges[r][0] if r != root else 0)
+        # (B) gather in pieces
+        stub.aa_stub_reset()
+        rows_np = [np.arange(f0 * cols, f1 * cols, dtype=np.float32) for f0, f1 in frames]
+        rows = [Dev(a.size, a) for a in rows_np]
+        out = Dev(total_frames * cols)
+        for k in range(P):
+            for r in order[::-1]:                                    # receives first this time
+                ok(lib.aa_gather_rows_piece(comms[r], rows[r].ptr if rows[r].n else None, total_frames, cols, root,
+                                            out.ptr if r == root and out.n else None, P, k, None))
+        L = log()
+        quiet(); pairs_up(L)
+        assert np.array_equal(out.get(), np.arange(total_frames * cols, dtype=np.float32))
+        want = [(r, *shard_piece(*frames[r], P, k)) for k in range(P) for r in range(world) if r != root]
+        want = [(r, q0, q1) for r, q0, q1 in want if q1 > q0]
+        assert sorted((e["rank"], (e["ptr"] - rows[e["rank"]].ptr) // (4 * cols) + frames[e["rank"]][0], e["count"] // cols)
+                      for e in L if e["op"] == "send") == sorted((r, q0, q1 - q0) for r, q0, q1 in want)
+        assert [(e["peer"], (e["ptr"] - out.ptr) // (4 * cols), (e["ptr"] - out.ptr) // (4 * cols) + e["count"] // cols)
+                for e in L if e["op"] == "recv"] == want
+        for b in local + rows + [out]:
+            b.free()
+        # (C) the pipeline, on one communicator and on two
+        for two in (False, True):
+            stub.aa_stub_reset()
+            if HOST_HIP:
+                hip.aa_hip_host_sync_reset()
+            USER = 7 if HOST_HIP else None                           # the caller's stream (the host stand-in takes any value)
+            local = [Dev(s1 - s0 + 3) for s0, s1 in ranges]
+            rows = [Dev((f1 - f0) * cols) for f0, f1 in frames]
+            out = Dev(total_frames * cols)
+            calls = {r: [] for r in range(world)}
+            spans = {}
+            for r in order:
+                def compute(user, fb, fe, stream, r=r):
+                    # rows[i][c] = 2 local[i hop + 3 c] + 1 for the piece's frames: right only if the piece's samples have landed
+                    hip.hipDeviceSynchronize()
+                    calls[r].append((fb, fe, stream, stub.aa_stub_log_count()))
+                    loc = local[r].get()
+                    part = np.stack([2.0 * loc[i * HOP + 3 * np.arange(cols)] + 1.0 for i in range(fb, fe)]).astype(np.float32)
+                    assert hip.hipMemcpy(rows[r].ptr + 4 * fb * cols, part.ctypes.data, 4 * part.size, 1) == 0
+                    return 0
+                cb = PIECE_FN(compute)
+                n0 = stub.aa_stub_log_count()
+                m0 = hip.aa_hip_host_sync_count() if HOST_HIP else 0
+                ok(lib.aa_sharded_pipeline(comms[r], (comms2 if two else comms)[r], full.ptr if r == root else None, n_samples,
+                                           N, HOP, cols, root, local[r].ptr, local[r].n, rows[r].ptr if rows[r].n else None,
+                                           out.ptr if r == root and out.n else None, P, cb, None, USER))
+                spans[r] = (n0, stub.aa_stub_log_count(), m0, hip.aa_hip_host_sync_count() if HOST_HIP else 0)
+            hip.hipDeviceSynchronize()
+            L = log()
+            quiet(); pairs_up(L)
+            expect = np.stack([2.0 * x[g * HOP + 3 * np.arange(cols)] + 1.0 for g in range(total_frames)]).astype(np.float32) \
+                if total_frames else np.zeros((0, cols), np.float32)
+            assert np.array_equal(out.get().reshape(-1, cols), expect), (world, total_frames, P, root, two)
+            S = sync_log() if HOST_HIP else []
+            for r in range(world):
+                f0, f1 = frames[r]
+                pieces = [shard_piece(f0, f1, P, k) for k in range(P)]
+                assert [(fb, fe) for fb, fe, _, _ in calls[r]] == [(a - f0, b - f0) for a, b in pieces if b > a]
+                assert all(st == USER for _, _, st, _ in calls[r])
+                # the rank's exchange list, in issue order: S0, S1, G0, S2, G1, .. - piece k's samples are posted before
+                # its compute is queued, its rows after, and the next piece's samples are already on their way
+                mine = L[spans[r][0]:spans[r][1]]
+                def S_ops(k):
+                    if r == root:
+                        return [("send", q, b - a) for q in range(world) if q != root
+                                for a, b in [piece_samples(*frames[q], P, k, N, HOP)] if b > a]
+                    a, b = piece_samples(f0, f1, P, k, N, HOP)
+                    return [("recv", root, b - a)] if b > a else []
+                def G_ops(k):
+                    if r == root:
+                        return [("recv", q, (q1 - q0) * cols) for q in range(world) if q != root
+                                for q0, q1 in [shard_piece(*frames[q], P, k)] if q1 > q0]
+                    q0, q1 = pieces[k]
+                    return [("send", root, (q1 - q0) * cols)] if q1 > q0 else []
+                want_ops, kinds, at_compute = S_ops(0), ["S"] * len(S_ops(0)), {}
+                for k in range(P):
+                    if k + 1 < P:
+                        want_ops += S_ops(k + 1); kinds += ["S"] * len(S_ops(k + 1))
+                    at_compute[k] = spans[r][0] + len(want_ops)
+                    want_ops += G_ops(k); kinds += ["G"] * len(G_ops(k))
+                assert [(e["op"], e["peer"], e["count"]) for e in mine] == want_ops, (world, r, P, root)
+                got_at = [c[3] for c in calls[r]]
+                assert got_at == [at_compute[k] for k in range(P) if pieces[k][1] > pieces[k][0]]
+                sin = {e["stream"] for e, kd in zip(mine, kinds) if kd == "S"}
+                sout = {e["stream"] for e, kd in zip(mine, kinds) if kd == "G"}
+                assert len(sin) <= 1 and len(sout) <= 1 and USER not in (sin | sout) or not HOST_HIP
+                if HOST_HIP and sin and sout:
+                    assert (sin != sout) == two                      # two communicators: two exchange streams
+                if HOST_HIP:
+                    # the wiring of the three streams, call by call
+                    seq = S[spans[r][2]:spans[r][3]]
+                    A = seq[1][1]                                    # the scatter stream: first to wait for the fork event
+                    B = seq[2][1] if two else A
+                    e0 = seq[0][2]
+                    assert seq[0] == ("rec", USER, e0) and seq[1] == ("wait", A, e0) and (not two or seq[2] == ("wait", B, e0))
+                    assert A != USER and B != USER and (A != B) == two
+                    body = seq[(3 if two else 2):]
+                    evs = []
+                    def take(kind, stream):
+                        entry = body[take.i]
+                        assert entry[:2] == (kind, stream), (entry, kind, stream, r, P)
+                        take.i += 1
+                        return entry[2]
+                    take.i = 0
+                    sev = {0: take("rec", A)}
+                    for k in range(P):
+                        if k + 1 < P:
+                            sev[k + 1] = take("rec", A)
+                        assert take("wait", USER) == sev[k]          # compute k behind its samples
+                        cev = take("rec", USER)
+                        assert take("wait", B) == cev                # gather k behind its rows
+                        evs.append(cev)
+                    j = take("rec", B)
+                    assert take("wait", USER) == j                   # the caller's stream continues behind the last gather
+                    if two:
+                        assert take("rec", A) == e0 and take("wait", USER) == e0
+                    assert take.i == len(body)
+                    assert len(set(sev.values()) | set(evs) | {j, e0}) == 2 * P + 2
+            for b in local + rows + [out]:
+                b.free()
+            checked += 1
+        full.free()
+    # argument checks: a piece index out of range, communicators of different ranks
+    assert lib.aa_scatter_samples_piece(comms[0], None, 0, N, HOP, 0, None, 0, 4, 4, None) == -1
+    assert lib.aa_gather_rows_piece(comms[0], None, 0, cols, 0, None, 0, 0, None) == -1
+    assert lib.aa_sharded_pipeline(comms[0], comms2[1], None, 0, N, HOP, cols, 0, None, 0, None, None, 4,
+                                   PIECE_FN(lambda *a: 0), None, None) == -1
+    assert stub.aa_stub_group_depth() == 0
     if HOST_HIP:
         h = ctypes.CDLL(None)
         assert h.aa_hip_host_current_device() == 0, "a collective left another device selected"
-    for c in comms:
+    for c in comms + comms2:
         ok(lib.aa_comm_destroy(c))
 print("scenarios", checked)
 '''
@@ -245,9 +448,9 @@ def run_child(tmp_path, host_hip):
 
 
 def test_comm_call_lists_worlds_2_3_8_host(tmp_path):
-    assert run_child(tmp_path, host_hip=True) == 3 * 4 * (2 + 2 * 3)
+    assert run_child(tmp_path, host_hip=True) == 3 * (4 * (2 + 2 * 3) + 6 * 2)
 
 
 @pytest.mark.gpu
 def test_comm_call_lists_worlds_2_3_8_device_buffers(tmp_path):
-    assert run_child(tmp_path, host_hip=False) == 3 * 4 * (2 + 2 * 3)
+    assert run_child(tmp_path, host_hip=False) == 3 * (4 * (2 + 2 * 3) + 6 * 2)

@@ -3,6 +3,7 @@
 the checker.  Tolerances: per frame max_k|out-ref| / max_k|ref| <= 1e-5 against the CPU
 restatement (BASELINE.json north_star), <= 5e-6 against the float64 truth; frame
 indexing exact."""
+import contextlib
 import os
 
 import numpy as np
@@ -1243,3 +1244,38 @@ def test_execute_device_rejects_unusable_out_buffers(aa, torch_mod):
         plan(x, frame_begin=3)                                               # host path: whole buffer only
     host_out = np.empty((100, 513), np.float32)
     assert plan(x, out=host_out) is host_out
+
+
+def test_execute_sharded_on_a_one_rank_communicator(aa, torch_mod):
+    """aa_stft_execute_sharded with the real runtime: RCCL communicators of one rank, the library's two exchange
+    streams, its events and the caller's compute stream.  Every piece count and both buffer arrangements (the root's
+    range and rows as views of the whole buffers, or as buffers of their own filled by device copies on the exchange
+    streams) must give the rows of one direct launch bit for bit - a missing event would let a piece be transformed
+    before its samples landed, or gathered before it was computed (the stub test pins the wiring, this runs it)."""
+    if "not found" in aa.Comm.backend():
+        pytest.skip("librccl not available: " + aa.Comm.backend())
+    n, hop = 1024, 256
+    plan = aa.Stft(n, hop, output="mag")
+    x = aa.signals.synth_corpus(3, n + 39_999 * hop + 77)
+    full = torch_mod.from_numpy(x).cuda()
+    ref = plan(full)
+    torch_mod.cuda.synchronize()
+    comm, comm2 = aa.Comm(aa.Comm.unique_id(), 1, 0), aa.Comm(aa.Comm.unique_id(), 1, 0)
+    side = torch_mod.cuda.Stream()
+    try:
+        for pieces in (1, 3, 8, 64):
+            for two in (False, True):
+                for alias in (True, False):
+                    for st in (None, side):
+                        out = torch_mod.full_like(ref, float("nan"))
+                        with torch_mod.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                            local, rows, got = comm.execute_sharded(plan, full, x.size, root=0, n_pieces=pieces,
+                                                                    comm_out=comm2 if two else None, out=out, alias=alias)
+                            # stream-ordered for the caller: work queued next on the same stream sees the slab
+                            check = got.clone()
+                        torch_mod.cuda.synchronize()
+                        assert torch_mod.equal(check, ref), (pieces, two, alias)
+                        assert torch_mod.equal(rows, ref) and torch_mod.equal(local, full[:local.numel()])
+    finally:
+        comm2.close()
+        comm.close()

@@ -57,6 +57,26 @@ def _worker(rank, world, port, n_samples, n_fft, hop, tmpdir):
         for i in (0, shard.local_frames - 1):
             g = shard.f0 + i
             assert np.array_equal(mine[i * hop:i * hop + n_fft], whole[g * hop:g * hop + n_fft])
+        # (d) the overlapped form - scatter k + 1 || compute k || gather k - 1 over pieces of every rank's range -
+        # yields the same slab bit for bit, for piece counts below, at and above the frames a rank owns; the
+        # pieces each rank transforms tile its range in order
+        for n_pieces, src in ((1, 0), (3, 0), (8, world - 1), (shard.local_frames + 5, 0)):
+            calls = []
+
+            def execute(local, fb, fe, rows_out):
+                calls.append((fb, fe))
+                part = oracle.stft(local.numpy()[fb * hop:(fe - 1) * hop + n_fft], n_fft, hop, kind="mag")
+                rows_out[fb:fe].copy_(torch.from_numpy(part))
+
+            full_src = torch.from_numpy(whole.copy()) if rank == src else None
+            loc, rws, slab = aa.overlapped_e2e(full_src, shard, execute, ref.shape[1], n_pieces=n_pieces, src=src)
+            assert np.array_equal(loc.numpy(), whole[shard.s0:shard.s1])
+            assert np.array_equal(rws.numpy(), ref[shard.f0:shard.f1])
+            assert (slab is not None) == (rank == src)
+            if rank == src:
+                assert np.array_equal(slab.numpy(), ref)
+            want = [aa.shard_piece(shard.f0, shard.f1, n_pieces, k) for k in range(n_pieces)]
+            assert calls == [(a - shard.f0, b - shard.f0) for a, b in want if b > a]
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -89,3 +109,28 @@ def test_shard_plan_properties():
     tiny = [aa.ShardPlan(1024 + 256, 1024, 256, 4, r) for r in range(4)]
     assert [p.local_frames for p in tiny] == [0, 1, 0, 1]
     assert all(p.local_samples == (1024 if p.local_frames else 0) for p in tiny)
+
+
+def test_pieces_tile_frames_and_samples():
+    """aa_shard_piece / piece_samples: the pieces of a frame range tile it, and the samples they add tile the
+    range's samples exactly (every sample travels once, consecutive pieces share the n_fft - hop halo)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import audio_analyzer_rs_amd as aa
+
+    for n_fft, hop in ((1024, 256), (2048, 512), (256, 64), (1024, 1000)):
+        for f0, f1 in ((0, 0), (5, 6), (100, 117), (0, 1000), (84_375, 168_750)):
+            s0, s1 = aa.shard_samples(f0, f1, n_fft, hop)
+            for P in (1, 2, 3, 8, 16, 64):
+                edge_f, edge_s = f0, s0
+                for k in range(P):
+                    p0, p1 = aa.shard_piece(f0, f1, P, k)
+                    a, b = aa.piece_samples(f0, f1, P, k, n_fft, hop)
+                    assert p0 == edge_f and p1 >= p0 and a == edge_s and b >= a
+                    if p1 > p0:                                  # the piece's frames are covered once it has landed
+                        assert b == (p1 - 1) * hop + n_fft and a <= p0 * hop + (n_fft - hop if k else 0)
+                    edge_f, edge_s = p1, b
+                assert edge_f == f1 and edge_s == s1
+    with pytest.raises(aa.AaError):
+        aa.shard_piece(0, 10, 4, 4)
