@@ -155,7 +155,7 @@ def cpu_baseline(x, min_seconds=8.0, max_reps=20):
 def load_traffic():
     """HBM bytes per launch of the headline kernel from the committed PMC passes (NOT measured in
     this run): (bytes, source file)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -437,7 +437,7 @@ def run_single(args):
 
     achieved_gbs = BYTES_PER_FRAME * nf / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = load_traffic()
-    sus = sustained_leg(timer, step, kernel_ms)
+    sus = sustained_leg(timer, step, kernel_ms, args.sustained_s)
     sus_gbs = BYTES_PER_FRAME * nf / (sus["ms_per_step"] * 1e-3) / 1e9
     ceil = copy_ceiling(torch, dev, timer, xd.shape[0], nf * plan.cols)
     result = {
@@ -909,6 +909,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config-steps", type=int, default=200, help="timed launches per entry of `configs`")
     ap.add_argument("--skip-cpu", action="store_true", help="omit the cpu_baseline / PCIe legs (profiling runs)")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the sustained leg (counter passes shorten it)")
     ap.add_argument("--skip-configs", action="store_true", help="headline kernel only (profiling runs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
