@@ -15,6 +15,8 @@ namespace aa {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kGemmK = 32;              // bins staged per LDS round
 constexpr int kGemmRows = 128;          // frames per workgroup (32 per wave)
@@ -402,16 +404,25 @@ constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
 // that a single live stream (the reference's shape: onset.rs runs one) no longer walks its frames in one wave at 0.7 us
 // each.  The per-bin floor recurrence (onset.rs:311-332) is independent per bin and feeds the frame only through the
 // burst count and the largest excess ratio; the scalar recurrences (energy EMA :345-350, FluxTracker :66-83, frame gate
-// :531-535) need only those two numbers.  Five waves, three phases, a block of kGateT frames apart each:
-//   waves 0-2  one lane per bin (<= 192 bins): the floor recurrence of block b, the bin's kGateT magnitudes in registers
-//              (the next block's prefetched from global memory), the ratio of every (frame, bin) into LDS
-//   wave 3     block b - 1: lanes = (frame, half of the bins) walk their column of ratios: count of ratios above
-//              BIN_BURST_RATIO and their maximum (order-free, so bit-identical to the sequential loop)
-//   wave 4     block b - 2: everything per frame that is no recurrence in the lanes (silence gate, burst trigger,
-//              velocity), then the three scalar chains frame by frame
-// One workgroup barrier per block.  Every f32 operation of a bin / of the chain is the reference's, in its order
-// (fp contract off): the outputs are bit-identical to onset_gates_kernel and to the C restatement.
+// :531-535) need only those two numbers.  Five waves, three roles, a block of kGateT frames apart each:
+//   A (3 waves) one lane per bin (<= 192 bins): the floor recurrence of block b, the bin's kGateT magnitudes in registers
+//               (the next block's prefetched from global memory), the ratio of every (frame, bin) into LDS
+//   R (1 wave)  block b - 1: lanes = (frame, half of the bins) walk their column of ratios: count of ratios above
+//               BIN_BURST_RATIO and their maximum (order-free, so bit-identical to the sequential loop); 32 reads in flight
+//   B (1 wave)  block b - 2: everything per frame that is no recurrence in the lanes (silence gate, burst trigger,
+//               velocity), then the recurrences: the energy EMA and the flux threshold are two INDEPENDENT chains of the
+//               same shape - s = s * (x > s ? k_rise : k_decay) + (x > s ? a_rise : a_decay) - so they run side by side in
+//               the two halves of the wave, one frame per step, operands from LDS rows, in VGPRs throughout (eight VALU
+//               instructions per frame; as wave-uniform scalars the compiler moved them through SGPRs and a branch: 404
+//               cycles per frame, tools/ubench_gate_chain.hip); the frames-since counter only moves at detected frames
+//               and is stepped on the scalar unit over the set bits of the block's detection mask.
+// A lone wave issues one instruction every ~4.4 cycles, so the roles are placed by SIMD: the workgroup's five waves land
+// on four SIMDs, the two that share one become R and B (their instruction counts per frame add up to about A's), the
+// three with a SIMD to themselves run A.  One workgroup barrier per block.  Every f32 operation of a bin / of the chains
+// is the reference's, in its order (fp contract off): the outputs are bit-identical to onset_gates_kernel and to the C
+// restatement.
 constexpr int kGateT = 32;
+constexpr int kGateOpsDwords = kGateT * 2 * 4 + kGateT * 2 * 2 + 8;   // operand rows, result rows, role table
 __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     const float *__restrict__ mags, const float *__restrict__ flux, const float *__restrict__ energy,
     const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     const uint8_t *__restrict__ suppress, int calibrated)
 {
 #pragma clang fp contract(off)
-    extern __shared__ float gate_lds[];
+    extern __shared__ __attribute__((aligned(16))) float gate_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (offsets) {
@@ -443,19 +454,51 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         initialized = init_flags ? init_flags[blockIdx.x] : 0;
     }
     // rows of the ratio image: n_bins columns + a spare one the lanes without a bin write to (no per-frame lane
-    // masks), an odd stride (the column walk of wave 3 is bank-conflict free)
+    // masks), an odd stride (the column walk of the R wave is bank-conflict free)
     const int stride = (n_bins + 1) | 1;
-    float *ratio = gate_lds;                         // [2][kGateT][stride]
-    int *cnts = reinterpret_cast<int *>(gate_lds + 2 * kGateT * stride);    // [2][kGateT]
+    float *ops = gate_lds;                           // [kGateT][2][4]: (x, a_rise, a_decay, clamp) of the EMA / of the threshold
+    float *res = ops + kGateT * 2 * 4;               // [kGateT][2][2]: (state behind the frame, x > state in front of it)
+    int *roles = reinterpret_cast<int *>(res + kGateT * 2 * 2);             // [8]
+    float *ratio = gate_lds + kGateOpsDwords;        // [2][kGateT][stride]
+    int *cnts = reinterpret_cast<int *>(ratio + 2 * kGateT * stride);      // [2][kGateT]
     float *maxs = reinterpret_cast<float *>(cnts + 2 * kGateT);            // [2][kGateT]
     const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
     const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
     const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
     const int64_t n_blocks = (n_frames + kGateT - 1) / kGateT;
 
+    // ---- roles by SIMD (HW_ID bits 5:4): 0..2 = A for bins 64 role .. 64 role + 63, 3 = R, 4 = B ----
+    if (lane == 0)
+        roles[wave] = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);
+    __syncthreads();
+    int role = wave;
+    {
+        int simd[5], n_on[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            simd[w] = __builtin_amdgcn_readfirstlane(roles[w]);
+            n_on[simd[w]] += 1;
+        }
+        int shared = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n_on[q] == 2 && n_on[(q + 1) & 3] == 1 && n_on[(q + 2) & 3] == 1 && n_on[(q + 3) & 3] == 1)
+                shared = q;
+        if (shared >= 0) {                           // (any other placement: roles by wave index, correct all the same)
+            int next_a = 0, next_rb = 3;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) {
+                const int r = simd[w] == shared ? next_rb++ : next_a++;
+                role = w == wave ? r : role;
+            }
+        }
+    }
+    role = __builtin_amdgcn_readfirstlane(role);
+    __syncthreads();
+
     // ---- state of the three roles ----
-    const int bin = 64 * wave + lane;
-    const bool valid = wave < 3 && bin < n_bins;
+    const int bin = 64 * role + lane;
+    const bool valid = role < 3 && bin < n_bins;
     const int col = valid ? bin : n_bins;            // (the spare column)
     float fl = valid ? state[bin] : 1.0f;
     float cur[kGateT], nxt[kGateT];
@@ -474,7 +517,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         }
         gfv = (lane < kGateT && t0 + lane < n_frames) ? global_floor[t0 + lane] : 0.0f;
     };
-    // wave 4: the per-frame inputs of a block, fetched a step ahead as well
+    // B: the per-frame inputs of a block, fetched a step ahead as well
     float b_flux = 0.0f, b_energy = 0.0f, n_flux = 0.0f, n_energy = 0.0f;
     int b_sup = 0, n_sup = 0;
     auto fetch_b = [&](int64_t b, float &vf, float &ve, int &vs) {
@@ -484,19 +527,21 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         ve = in ? energy[t] : 0.0f;
         vs = (in && suppress) ? (int)suppress[t] : 0;
     };
-    float ema = 0.0f, thr = 0.0f;
+    // B: lanes 0-31 carry the energy EMA, lanes 32-63 the flux threshold (the same instruction stream for both)
+    const int grp = lane >> 5;
+    float chain_s = 0.0f;
+    const float k_rise = grp ? rise_memory : ENERGY_EMA_RISE, k_decay = grp ? decay_memory : ENERGY_EMA_DECAY;
     int since = 4;
     if (initialized) {
-        ema = state[n_bins];
-        thr = state[n_bins + 1];
-        since = __float_as_int(state[n_bins + 2]);
+        chain_s = grp ? state[n_bins + 1] : state[n_bins];
+        since = __builtin_amdgcn_readfirstlane(__float_as_int(state[n_bins + 2]));
     }
-    if (wave < 3 && n_blocks > 0) {
+    if (role < 3 && n_blocks > 0) {
         fetch(0, cur, cur_gf);
         if (!initialized)                            // onset.rs:304-309: the floors start at the first frame's magnitudes
             fl = fmaxf(cur[0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), 0)));
     }
-    if (wave == 4 && n_blocks > 0)
+    if (role == 4 && n_blocks > 0)
         fetch_b(0, b_flux, b_energy, b_sup);
 
     // one frame of one bin (onset.rs:311-332), branch-free: the three candidate floors, two selects
@@ -511,7 +556,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     };
 
     for (int64_t step = 0; step < n_blocks + 2; ++step) {
-        if (wave < 3) {
+        if (role < 3) {
             // ---- per-bin floor recurrence of block `step` ----
             if (step < n_blocks) {
                 if (step + 1 < n_blocks)
@@ -537,7 +582,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                     cur[i] = nxt[i];
                 cur_gf = nxt_gf;
             }
-        } else if (wave == 3) {
+        } else if (role == 3) {
             // ---- burst count and largest excess of every frame of block `step - 1` ----
             if (step >= 1 && step <= n_blocks) {
                 const int pb = (int)((step - 1) & 1);
@@ -548,7 +593,19 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 int count = 0;
                 float mx = 0.0f;
                 int k = k0;
-                for (; k + 8 <= k1; k += 8) {        // eight reads in flight
+                // thirty-two reads in flight: a lone wave sees the whole LDS round trip on every wait
+                for (; k + 32 <= k1; k += 32) {
+                    float r[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j)
+                        r[j] = colp[k + j];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        count += r[j] > BIN_BURST_RATIO ? 1 : 0;
+                        mx = r[j] > mx ? r[j] : mx;
+                    }
+                }
+                for (; k + 8 <= k1; k += 8) {
                     float r[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
@@ -573,7 +630,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 }
             }
         } else {
-            // ---- the frame's gates and the scalar chains of block `step - 2` ----
+            // ---- the frame's gates and the recurrences of block `step - 2` ----
             if (step >= 2) {
                 const int64_t b = step - 2, t0 = b * kGateT;
                 const int pb = (int)(b & 1);
@@ -590,48 +647,90 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 // 381-382) and the products the two memories may pick from (the reference's own operands: x * (1 - memory))
                 if (count < 2)
                     v_flux = 0.0f;
-                const int bo_l = (mx > 3.0f && count >= 3) ? 1 : 0;
+                const bool bo = mx > 3.0f && count >= 3;
                 float vel = fmaxf(v_flux, mx * 5.0f) / 50.0f;
                 vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
-                const float e_rise = v_energy * (1.0f - ENERGY_EMA_RISE), e_dec = v_energy * (1.0f - ENERGY_EMA_DECAY);
-                const float f_rise = v_flux * (1.0f - rise_memory), f_dec = v_flux * (1.0f - decay_memory);
-                float o_ema = 0.0f;
-                int o_flags = 0;
-                auto lane_f = [&](float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
-                auto chain = [&](int i) {
-                    const float current_flux = lane_f(v_flux, i), frame_energy = lane_f(v_energy, i);
-                    const bool bo = __builtin_amdgcn_readlane(bo_l, i) != 0;
-                    const bool sup = __builtin_amdgcn_readlane(v_sup, i) != 0;
-                    const bool up = frame_energy > ema;
-                    ema = ema * (up ? ENERGY_EMA_RISE : ENERGY_EMA_DECAY) + (up ? lane_f(e_rise, i) : lane_f(e_dec, i));
-                    const bool is_onset = current_flux > thr;
-                    thr = thr * (is_onset ? rise_memory : decay_memory) + (is_onset ? lane_f(f_rise, i) : lane_f(f_dec, i));
-                    thr = thr < 0.9f ? 0.9f : thr;
-                    const bool flux_onset = is_onset && current_flux > thr * multiplier;
-                    const bool detected = flux_onset && bo;
-                    const bool rising = frame_energy > ema * 1.5f;
-                    const bool tick = detected && sup;
-                    const bool fired = detected && !tick && rising && since >= 3 && calibrated != 0;
-                    since = (fired || (detected && since < 3)) ? 0 : (since < 0x7fffffff ? since + 1 : since);
-                    const int fl_bits = (int)flux_onset | ((int)bo << 1) | ((int)detected << 2) | ((int)rising << 3) |
-                                        ((int)fired << 4) | ((int)tick << 5);
-                    o_ema = lane == i ? ema : o_ema;
-                    o_flags = lane == i ? fl_bits : o_flags;
+                if (lane < kGateT) {
+                    v4f *row = reinterpret_cast<v4f *>(ops + 8 * lane);
+                    row[0] = v4f{v_energy, v_energy * (1.0f - ENERGY_EMA_RISE), v_energy * (1.0f - ENERGY_EMA_DECAY), -INFINITY};
+                    row[1] = v4f{v_flux, v_flux * (1.0f - rise_memory), v_flux * (1.0f - decay_memory), 0.9f};
+                }
+                __builtin_amdgcn_wave_barrier();
+                // the two recurrences, one frame per step.  The row addresses go through an opaque VGPR: as wave-uniform
+                // values the operands would be loaded into SGPRs and every compare / select of the chain would take the
+                // VALU -> SGPR -> VALU detour again.
+                unsigned row_off = 16u * (unsigned)grp, res_off = 8u * (unsigned)grp;
+                asm volatile("" : "+v"(row_off), "+v"(res_off));
+                const char *ops_b = reinterpret_cast<const char *>(ops) + row_off;
+                char *res_b = reinterpret_cast<char *>(res) + res_off;
+                auto chain = [&](const v4f o, int i) {                  // o: x, a_rise, a_decay, clamp
+                    const bool up = o.x > chain_s;
+                    chain_s = chain_s * (up ? k_rise : k_decay) + (up ? o.y : o.z);
+                    chain_s = chain_s < o.w ? o.w : chain_s;          // (the threshold's 0.9 floor; -inf for the EMA)
+                    *reinterpret_cast<v2f *>(res_b + 16 * i) = v2f{chain_s, up ? 1.0f : 0.0f};
                 };
                 if (nfb == kGateT) {
+                    // operand rows eight frames at a time, the next eight in flight while these are stepped (the reads
+                    // stand in front of the result writes in program order: the compiler need not reorder LDS accesses
+                    // it cannot tell apart, and the wave does not sit out an LDS round trip per frame)
+                    v4f o[2][8];
 #pragma unroll
-                    for (int i = 0; i < kGateT; ++i)
-                        chain(i);
+                    for (int j = 0; j < 8; ++j)
+                        o[0][j] = *reinterpret_cast<const v4f *>(ops_b + 32 * j);
+#pragma unroll
+                    for (int k = 0; k < kGateT / 8; ++k) {
+                        if (k + 1 < kGateT / 8) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                o[(k + 1) & 1][j] = *reinterpret_cast<const v4f *>(ops_b + 32 * (8 * (k + 1) + j));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            chain(o[k & 1][j], 8 * k + j);
+                    }
                 } else {
                     for (int i = 0; i < nfb; ++i)
-                        chain(i);
+                        chain(*reinterpret_cast<const v4f *>(ops_b + 32 * i), i);
                 }
+                __builtin_amdgcn_wave_barrier();
+                // back to lane = frame: the frame's flags from the two states behind it
+                const int fr = lane < kGateT ? lane : 0;
+                const v2f r_ema = *reinterpret_cast<const v2f *>(res + 4 * fr), r_thr = *reinterpret_cast<const v2f *>(res + 4 * fr + 2);
+                const float ema_i = r_ema.x, thr_i = r_thr.x;
+                const bool is_onset = r_thr.y != 0.0f;
+                const bool flux_onset = mine && is_onset && v_flux > thr_i * multiplier;
+                const bool detected = flux_onset && bo;
+                const bool rising = v_energy > ema_i * 1.5f;
+                const bool tick = detected && v_sup != 0;
+                const bool armed = detected && !tick && rising && calibrated != 0;       // fires if >= 3 frames since the last one
+                // frames since the last onset: + 1 per frame, except at a detected frame (0 when it fires or comes
+                // within 3 frames of the last one) - stepped over the set bits of the block's detection mask
+                const uint64_t det_mask = __ballot(detected), arm_mask = __ballot(armed);
+                uint64_t fired_mask = 0, todo = det_mask;
+                int at = 0;                                             // frames of the block already counted
+                auto advance = [&](int n) { since = since > 0x7fffffff - n ? 0x7fffffff : since + n; };
+                while (todo) {
+                    const int i = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    advance(i - at);
+                    const bool f = ((arm_mask >> i) & 1) != 0 && since >= 3;
+                    fired_mask |= (uint64_t)f << i;
+                    if (f || since < 3)
+                        since = 0;
+                    else
+                        advance(1);
+                    at = i + 1;
+                }
+                advance(nfb - at);
+                const bool fired = ((fired_mask >> lane) & 1) != 0;
+                const int fl_bits = (int)flux_onset | ((int)bo << 1) | ((int)detected << 2) | ((int)rising << 3) |
+                                    ((int)fired << 4) | ((int)tick << 5);
                 if (mine) {
                     out_flux[t0 + lane] = v_flux;
-                    out_ema[t0 + lane] = o_ema;
+                    out_ema[t0 + lane] = ema_i;
                     out_excess[t0 + lane] = mx;
                     out_count[t0 + lane] = count;
-                    out_flags[t0 + lane] = (uint8_t)o_flags;
+                    out_flags[t0 + lane] = (uint8_t)fl_bits;
                     out_velocity[t0 + lane] = vel;
                 }
                 b_flux = n_flux;
@@ -643,10 +742,13 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     }
     if (valid)
         state[bin] = fl;
-    if (wave == 4 && lane == 0) {
-        state[n_bins] = ema;
-        state[n_bins + 1] = thr;
-        state[n_bins + 2] = __int_as_float(since);
+    if (role == 4) {
+        if (lane == 0)
+            state[n_bins] = chain_s;
+        if (lane == 32)
+            state[n_bins + 1] = chain_s;
+        if (lane == 0)
+            state[n_bins + 2] = __int_as_float(since);
     }
 }
 
@@ -1044,7 +1146,7 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
     // ten-minute stream: 313 -> ~30 ms); many streams already fill the chip with one wave each
     if (n_bins <= 192 && n_streams < 256) {
         const int stride = (n_bins + 1) | 1;
-        const size_t lds2 = sizeof(float) * (size_t)(2 * kGateT * stride + 4 * kGateT);
+        const size_t lds2 = sizeof(float) * (size_t)(kGateOpsDwords + 2 * kGateT * stride + 4 * kGateT);
         hipLaunchKernelGGL(onset_gates_split_kernel, dim3((unsigned)n_streams), dim3(320), lds2, stream, mags, flux, energy,
                            global_floor, state, initialized, n_frames, n_bins, out_flux, out_ema, out_excess, out_count,
                            out_flags, out_velocity, offsets, init_flags, suppress, calibrated);
