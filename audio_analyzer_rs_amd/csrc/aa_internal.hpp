@@ -88,6 +88,9 @@ constexpr int kMelLdsDwords = kMelParTableDwords + 4 * kMelStageDwords;
 constexpr int kMfccRowStride = 132;
 constexpr int kMfccLdsDwords = 16 * kMfccRowStride;
 constexpr int kMfccTiles = 4;
+// the coefficients of a 16-frame block leave through an LDS tile [16][n_mfcc] (the block's rows are one contiguous span of
+// the output: coalesced stores by the whole workgroup instead of four scattered dwords per lane)
+constexpr int kMfccOutTileDwords = 16 * 16 * kMfccTiles;
 constexpr int kMfccTableDwords = kMfccTiles * 4 * 64 * 4;
 struct MelSched {
     int n_mels = 0;
@@ -144,7 +147,7 @@ inline int64_t wave1024_lds_dwords(int frames_per_wg, int hop, int mel = 0)
     const int64_t span = (int64_t)(frames_per_wg - 1) * hop + 1024;
     // (the partial sums of the mel contraction live in the chunk's dead sample buffer when it is large enough)
     if (mel >= 3)
-        return 2 * span + 4 * kMelMfmaScratchDwords + (mel == 4 ? kMfccLdsDwords : 0) + 4 +
+        return 2 * span + 4 * kMelMfmaScratchDwords + (mel == 4 ? kMfccLdsDwords + kMfccOutTileDwords : 0) + 4 +
                (span < kMelMfmaPartDwords ? kMelMfmaPartDwords : 0);       // (+ 4: the zero slot of the slice sums)
     return 2 * span + 4 * kWave1024ScratchDwords + (mel ? kMelLdsDwords : 0);
 }

@@ -1076,8 +1076,8 @@ void stft_wave1024_kernel(
 // chunk c + 1 (frame reads, window, pass A - registers only) inside the phase between B1 and T, to fill its chain of
 // latencies: 85.4 us against 77.2 (the exchanges' LDS round trip is then exposed at the chunk top, and the LDS-DMA has
 // half a chunk instead of a whole one to land: 82.7 us without any DMA).
-// LDS: [2][span] samples | 4 x kMelMfmaScratchDwords | kMfccM: the log-mel block [16][kMfccRowStride] | a zero
-// float4 | the partial sums when a sample buffer is too small for them (hops below 147).
+// LDS: [2][span] samples | 4 x kMelMfmaScratchDwords | kMfccM: the log-mel block [16][kMfccRowStride], the coefficient
+// tile [16][n_mfcc] | a zero float4 | the partial sums when a sample buffer is too small for them (hops below 147).
 #ifndef AA_MELP_PRIO
 #define AA_MELP_PRIO 2103  // r4: 74.7 us against 78.8 with the rotation (log-mel), 84.8 against 91.0 (MFCC); 3210 75.5, 3103 / 3203 / 2102 within 0.5 % of 2103, 2113 / 2003 / 1003 lose 5 %
 #endif
@@ -1131,7 +1131,8 @@ void stft_wave1024_mel_kernel(
     float *scr0 = smem + 2 * max_span;
     v2f *scr = reinterpret_cast<v2f *>(scr0 + wave * kScr);
     float *lm = scr0 + 4 * kScr;                             // kMfccM: log-mel rows of two chunks
-    float *tail = lm + (MFCC ? kMfccLdsDwords : 0);          // [zero float4][partial sums, if not in a sample buffer]
+    float *ctile = lm + (MFCC ? kMfccLdsDwords : 0);         // kMfccM: coefficients of a 16-frame block, [16][n_mfcc]
+    float *tail = ctile + (MFCC ? kMfccOutTileDwords : 0);   // [zero float4][partial sums, if not in a sample buffer]
     const int COLS = MFCC ? n_mfcc : n_mels;
     const int64_t first_frame = (int64_t)c0 * FPW;
     const float *src_chunk = x + (frame_begin + first_frame) * (int64_t)hop;   // samples of chunk c
@@ -1262,23 +1263,40 @@ void stft_wave1024_mel_kernel(
             lrow[513 + lane] = 0.0f;
     };
 
-    // kMfccM: accumulators of the last DCT block, stored from the top of the next chunk (the MFMAs drain meanwhile)
+    // kMfccM: the accumulators of the last DCT block go to the coefficient tile at the top of the next chunk (the MFMAs
+    // drain meanwhile); behind that chunk's barrier B1 the whole workgroup copies the tile - the block's 16 rows are ONE
+    // contiguous span of the output - with coalesced stores (four scattered dwords per lane before: -5 us per launch)
     v4f pend0 = {0.0f, 0.0f, 0.0f, 0.0f}, pend1 = pend0;
-    float *pend_row = nullptr;
-    int pend_coef0 = 0;
-    bool pending = false;
+    bool pending = false;                                    // accumulators not yet in the tile
+    float *tile_dst = nullptr;                               // where the tile's block starts in the output, and
+    int tile_floats = 0;                                     // how many of its floats are rows that exist (0: nothing to copy)
     auto flush_dct = [&]() {
         if (MFCC && pending) {
             const v4f d = pend0 + pend1;
-            if (pend_row) {
-                if (pend_coef0 + 0 < n_mfcc) pend_row[0] = d.x;
-                if (pend_coef0 + 2 < n_mfcc) pend_row[2] = d.y;
-                if (pend_coef0 + 4 < n_mfcc) pend_row[4] = d.z;
-                if (pend_coef0 + 6 < n_mfcc) pend_row[6] = d.w;
-            }
+            // D layout of the 16 x 16 x 4 MFMA: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
+            const int coef0 = 2 * (16 * (wave & 1) + 4 * (lane >> 4)) + (wave >> 1);
+            float *t = ctile + (lane & 15) * COLS + coef0;
+            if (coef0 + 0 < n_mfcc) t[0] = d.x;
+            if (coef0 + 2 < n_mfcc) t[2] = d.y;
+            if (coef0 + 4 < n_mfcc) t[4] = d.z;
+            if (coef0 + 6 < n_mfcc) t[6] = d.w;
             pending = false;
         }
     };
+    auto store_tile = [&]() {                                // (behind a workgroup barrier that follows flush_dct)
+        if (MFCC && tile_floats > 0) {
+            for (int i = tid; i < tile_floats; i += kWave1024Threads)
+                tile_dst[i] = ctile[i];
+            tile_floats = 0;
+        }
+    };
+    // kMfccM: the A operand of the DCT (the wave's 16 coefficients x 64 folded mel bands) stays in registers: fetched per
+    // block from the plan's table it cost 4 us per launch (its wait also covers whatever vector-memory work is in flight)
+    v4f a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+    if (MFCC) {
+        const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + lane;
+        a0 = at[0]; a1 = at[64]; a2 = at[128]; a3 = at[192];
+    }
 
     // ---- prologue: chunk c0 has landed ----
     wait_vmcnt_le<0>();
@@ -1320,6 +1338,7 @@ void stft_wave1024_mel_kernel(
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();        // B1: the eight power rows are written, chunk c + 1 has landed
         mel_prio(3, prio_step);
+        store_tile();                        // kMfccM: the block the DCT finished a chunk ago
 
         // ---- the mel contraction of chunk c with the front half of chunk c + 1 inside it ----
         int ln = lane;
@@ -1383,16 +1402,8 @@ void stft_wave1024_mel_kernel(
             }
         }
         const bool dct_now = MFCC && ((it & 1) || !has_next);
-        // kMfccM: the A operand of the DCT (plan table, L2 resident) is fetched in front of the barrier
-        v4f a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
-        if (dct_now) {
-            const v4f *at = reinterpret_cast<const v4f *>(dct_tab) + (wave * 4) * 64 + ln;
-            a0 = at[0]; a1 = at[64]; a2 = at[128]; a3 = at[192];
-        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();        // T: every wave is done with the rows, the partial sums and the sample buffer
-        // (the LDS-DMA of chunk c + 2 is issued BEHIND the DCT phase: vmcnt retires in order and the compiler's wait for the
-        // DCT's A operand, fetched above, would otherwise cover the fresh DMA)
         if (dct_now) {
             // ---- DCT-II of the block of (up to) 16 frames on the f32 matrix cores (see stft_wave1024_kernel): wave w owns
             // the 16 coefficients c = 2 (16 (w & 1) + i) + (w >> 1); the fold about the middle of the mel axis happens in the
@@ -1428,17 +1439,12 @@ void stft_wave1024_mel_kernel(
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, bb[3].z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bb[2].w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, bb[3].w, acc1, 0, 0, 0);
-            // D layout: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
-            const int j = ln & 15, coef0 = 2 * (16 * (wave & 1) + 4 * (ln >> 4)) + (wave >> 1);
-            const int have = (it & 1) ? 8 + nf : nf;               // valid rows (a lone last chunk: rows 0..7)
-            // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's
-            float *orow = ((it & 1) ? (j < 8 ? out_chunk - out_stride + j * COLS : out_chunk + (j - 8) * COLS)
-                                    : out_chunk + j * COLS) + coef0;
+            // rows 0..7 of a full block are the previous chunk's frames, rows 8..15 this chunk's (a lone last chunk: rows 0..7)
             pend0 = acc0;
             pend1 = acc1;
-            pend_row = j < have ? orow : nullptr;
-            pend_coef0 = coef0;
             pending = true;
+            tile_dst = (it & 1) ? out_chunk - out_stride : out_chunk;
+            tile_floats = ((it & 1) ? 8 + nf : nf) * COLS;
         }
         if (c + 2 < c1) {
             const int nleft = frames_left - 2 * FPW;
@@ -1448,7 +1454,11 @@ void stft_wave1024_mel_kernel(
         out_chunk += out_stride;
         frames_left -= FPW;
     }
-    flush_dct();
+    if (MFCC) {
+        flush_dct();
+        __syncthreads();
+        store_tile();
+    }
 }
 
 // ---------------------------------------------------- wave-per-frame, n_fft = 2048 --
