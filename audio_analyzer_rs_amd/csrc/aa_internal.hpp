@@ -79,18 +79,20 @@ constexpr int kMelParDwords = 6;
 constexpr int kMelParTableDwords = (kMelMaxMels + 1) * kMelParDwords + 2;   // 776, keeps 16-byte size
 constexpr int kMelStageDwords = 256;                // per wave: mel values of up to two frames
 constexpr int kMelLdsDwords = kMelParTableDwords + 4 * kMelStageDwords;
-// kMfccM: log-mel rows of two chunks (16 frames) in LDS, row stride 132 floats (the B-operand reads of the DCT's MFMA -
-// 16 frames x 4 K-groups, 16 bytes each - then spread over all 64 banks); the fold about the middle of the mel axis
+// kMfccM: log-mel rows of two chunks (16 frames) in LDS, row stride 136 floats and the columns of rows 4..7 / 12..15
+// swizzled (col ^ 4): the B-operand reads of the DCT's MFMA - 16 frames x 4 K-groups, 16 bytes each - and the row writes
+// are then conflict free on the lane groups the hardware serves ds_read_b128 / ds_write_b128 in (r4; 132 floats before,
+// chosen for consecutive 16-lane groups, which they are not); the fold about the middle of the mel axis
 // (u = L[m] + L[M-1-m] for the even coefficients, v = L[m] - L[M-1-m] for the odd ones: the DCT-II matrix is symmetric /
 // antisymmetric there) happens in the B operand.  The DCT matrix comes as a per-lane table [tile][4][64] float4:
 // tile = (parity, half) = 16 coefficients c = 2 (16 half + i) + parity, K ordered m = 16 S + 4 (lane / 16) + t: 4 tiles =
 // up to 64 coefficients, n_mels % 4 == 0 and <= 128.
-constexpr int kMfccRowStride = 132;
+constexpr int kMfccRowStride = 136;   // (B-operand reads conflict free on the hardware lane groups of ds_read_b128; r2-r3: 132)
 constexpr int kMfccLdsDwords = 16 * kMfccRowStride;
 constexpr int kMfccTiles = 4;
 // the coefficients of a 16-frame block leave through an LDS tile [16][n_mfcc] (the block's rows are one contiguous span of
 // the output: coalesced stores by the whole workgroup instead of four scattered dwords per lane)
-constexpr int kMfccOutTileDwords = 16 * 16 * kMfccTiles;
+constexpr int kMfccOutTileDwords = 16 * (16 * kMfccTiles + 1) + 12;      // row stride n_mfcc | 1 (bank spread); a multiple of 4 dwords
 constexpr int kMfccTableDwords = kMfccTiles * 4 * 64 * 4;
 struct MelSched {
     int n_mels = 0;
@@ -126,7 +128,11 @@ constexpr int kMelMfmaScratchDwords = 1072;         // scratch stride of these k
                                                     // frames a block reads sit in four different bank quarters
 constexpr int kMelMfmaWaveDwords = kMelMfmaSteps * 64 * 4 + 2 * 64;
 constexpr int kMelMfmaTableDwords = 4 * kMelMfmaWaveDwords;
-constexpr int kMelMfmaPartDwords = 4 * 2 * 64 * 4;  // partial sums of a workgroup: [wave][frame set][lane][4]
+// partial sums of a workgroup: [wave][frame set][lane][4].  The second frame set (frames 4..7) starts 64 + 4 d float4
+// behind the first, d = 0..3 from bits 14-15 of the wave's emission words: the shift that spreads a slot's two sets
+// over the 16-byte bank slots of a ds_read_b128 lane group for the wave's mix of slice counts (build_mel_mfma)
+constexpr int kMelMfmaPartWaveDwords = (64 + 12 + 64) * 4;
+constexpr int kMelMfmaPartDwords = 4 * kMelMfmaPartWaveDwords;
 // the 2048 kernel (hop 512, 4 frames per chunk = the 4 columns of a block: one frame set, 8 emission slots of 4 frames x
 // the two halves of a quad per wave; up to 7 steps of resident weights; same per-wave table layout)
 constexpr int kMelMfmaSteps2048 = 7;

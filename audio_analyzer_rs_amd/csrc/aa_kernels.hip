@@ -1269,13 +1269,14 @@ void stft_wave1024_mel_kernel(
     v4f pend0 = {0.0f, 0.0f, 0.0f, 0.0f}, pend1 = pend0;
     bool pending = false;                                    // accumulators not yet in the tile
     float *tile_dst = nullptr;                               // where the tile's block starts in the output, and
-    int tile_floats = 0;                                     // how many of its floats are rows that exist (0: nothing to copy)
+    int tile_rows = 0;                                       // how many of its rows exist (0: nothing to copy)
+    const int tile_stride = COLS | 1;                        // odd: the accumulator writes spread over the banks (two-way at worst)
     auto flush_dct = [&]() {
         if (MFCC && pending) {
             const v4f d = pend0 + pend1;
             // D layout of the 16 x 16 x 4 MFMA: lane = (4-row group lane / 16, frame j = lane % 16), register r = row in the group
             const int coef0 = 2 * (16 * (wave & 1) + 4 * (lane >> 4)) + (wave >> 1);
-            float *t = ctile + (lane & 15) * COLS + coef0;
+            float *t = ctile + (lane & 15) * tile_stride + coef0;
             if (coef0 + 0 < n_mfcc) t[0] = d.x;
             if (coef0 + 2 < n_mfcc) t[2] = d.y;
             if (coef0 + 4 < n_mfcc) t[4] = d.z;
@@ -1284,10 +1285,12 @@ void stft_wave1024_mel_kernel(
         }
     };
     auto store_tile = [&]() {                                // (behind a workgroup barrier that follows flush_dct)
-        if (MFCC && tile_floats > 0) {
-            for (int i = tid; i < tile_floats; i += kWave1024Threads)
-                tile_dst[i] = ctile[i];
-            tile_floats = 0;
+        if (MFCC && tile_rows > 0) {                        // wave w: rows 4 w .. 4 w + 3, one coalesced piece of n_mfcc floats each
+#pragma unroll
+            for (int r = 4 * wave; r < 4 * wave + 4; ++r)
+                if (r < tile_rows && lane < COLS)
+                    tile_dst[r * COLS + lane] = ctile[r * tile_stride + lane];
+            tile_rows = 0;
         }
     };
     // kMfccM: the A operand of the DCT (the wave's 16 coefficients x 64 folded mel bands) stays in registers: fetched per
@@ -1364,17 +1367,18 @@ void stft_wave1024_mel_kernel(
         }
         // partial sums of (block, frame) -> LDS: this chunk's sample buffer is dead (every wave read its frames a chunk
         // ago; the next LDS-DMA into it is issued behind barrier T)
-        float *part = (max_span >= kMelMfmaPartDwords ? smem + cur * max_span : tail + 4) + wave * (2 * 64 * 4);
+        float *part = (max_span >= kMelMfmaPartDwords ? smem + cur * max_span : tail + 4) + wave * kMelMfmaPartWaveDwords;
         v4f *p4 = reinterpret_cast<v4f *>(part);
-        p4[ln] = d0;
-        p4[64 + ln] = d1;
-        __builtin_amdgcn_wave_barrier();
-        // lanes re-labelled (quad slot, frame f = lane % 8): the slices of the quad (consecutive blocks), four per round
         unsigned em = mmf.emit;
         asm volatile("" : "+v"(em));
+        const int set1 = 64 + 4 * __builtin_amdgcn_readfirstlane((int)(em >> 14) & 3);   // second frame set (aa_internal.hpp)
+        p4[ln] = d0;
+        p4[set1 + ln] = d1;
+        __builtin_amdgcn_wave_barrier();
+        // lanes re-labelled (quad slot, frame f = lane % 8): the slices of the quad (consecutive blocks), four per round
         const int ns = (int)(em & 31u), blk0 = (int)((em >> 5) & 15u);
         const int hmax = __builtin_amdgcn_readfirstlane((int)(em >> 24) & 31);
-        const v4f *src = p4 + ((ln & 4) << 4) + 4 * blk0 + (ln & 3);      // set f / 4, lane 4 blk0 + f % 4
+        const v4f *src = p4 + ((ln & 4) ? set1 : 0) + 4 * blk0 + (ln & 3);      // set f / 4, lane 4 blk0 + f % 4
         const v4f *z4 = reinterpret_cast<const v4f *>(tail);
         v4f m4 = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int h0 = 0; h0 < hmax; h0 += 4) {
@@ -1398,7 +1402,9 @@ void stft_wave1024_mel_kernel(
                     *reinterpret_cast<v4f *>(out_chunk + __mul24(f, COLS) + q4) = l4;
             } else {
                 // row 8 (chunk parity) + frame of the log-mel block (rows 0..7 were read by the DCT a chunk pair ago)
-                *reinterpret_cast<v4f *>(lm + (8 * (it & 1) + f) * kMfccRowStride + q4) = l4;
+                // (columns swizzled by the row's bit 2 - adjacent quads swapped in rows 4..7 and 12..15: with the 136-float
+                // stride both this write and the DCT's B-operand reads are conflict free on the hardware's lane groups)
+                *reinterpret_cast<v4f *>(lm + (8 * (it & 1) + f) * kMfccRowStride + (q4 ^ (f & 4))) = l4;
             }
         }
         const bool dct_now = MFCC && ((it & 1) || !has_next);
@@ -1417,8 +1423,8 @@ void stft_wave1024_mel_kernel(
                 const int ma = 16 * S + mq;
                 int mb = n_mels - 4 - ma;
                 mb = mb < 0 ? ma : mb;
-                const v4f a = *reinterpret_cast<const v4f *>(rowp + ma);
-                const v4f r = *reinterpret_cast<const v4f *>(rowp + mb);
+                const v4f a = *reinterpret_cast<const v4f *>(rowp + (ma ^ (ln & 4)));      // (the row's column swizzle)
+                const v4f r = *reinterpret_cast<const v4f *>(rowp + (mb ^ (ln & 4)));
                 bb[S] = (wave >> 1) ? v4f{a.x - r.w, a.y - r.z, a.z - r.y, a.w - r.x}
                                     : v4f{a.x + r.w, a.y + r.z, a.z + r.y, a.w + r.x};
             }
@@ -1444,7 +1450,7 @@ void stft_wave1024_mel_kernel(
             pend1 = acc1;
             pending = true;
             tile_dst = (it & 1) ? out_chunk - out_stride : out_chunk;
-            tile_floats = ((it & 1) ? 8 + nf : nf) * COLS;
+            tile_rows = (it & 1) ? 8 + nf : nf;
         }
         if (c + 2 < c1) {
             const int nleft = frames_left - 2 * FPW;
