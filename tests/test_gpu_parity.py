@@ -986,6 +986,39 @@ def test_full_size_sharded_equals_whole(aa, torch_mod, corpus_10min):
         assert torch_mod.equal(torch_mod.cat(parts), whole)
 
 
+def test_config3_one_hour_sizes_as_eight_shards_on_one_gpu(aa, oracle_mod, torch_mod, corpus_10min):
+    """BASELINE configs[3] at its FULL size on the one GPU a test box has: 172.8 M samples (1 h at 48 kHz; the
+    10-minute corpus six times over - synthesising the hour on the host would take a minute, and any signal of that
+    length exercises the same indices), 674 997 frames, as one launch and as the eight frame-range shards of
+    aa_shard_frames / aa_shard_samples (84 375 +- 1 frames, 768-sample halo).  The shards' rows are the whole
+    launch's rows bit for bit; both edges of every shard agree with the float64 definition; the 64-bit frame /
+    sample arithmetic holds at 1.385 GB of output.  (Eight GPUs moving these shards over xGMI is the driver's run.)"""
+    x10, xd10 = corpus_10min
+    n, hop, world = 1024, 256, 8
+    xd = xd10.repeat(6)
+    total = xd.shape[0]
+    assert total == 172_800_000
+    plan = aa.Stft(n, hop, output="mag")
+    nf = plan.num_frames(total)
+    assert nf == 674_997
+    whole = plan(xd)
+    shards = [aa.ShardPlan(total, n, hop, world, r) for r in range(world)]
+    assert sum(sp.local_frames for sp in shards) == nf and all(abs(sp.local_frames - 84_375) <= 1 for sp in shards)
+    w = oracle_mod.hann_window(n)
+    for sp, nxt in zip(shards, shards[1:] + [None]):
+        if nxt is not None:
+            assert sp.f1 == nxt.f0 and sp.s1 - nxt.s0 == n - hop
+        local = xd[sp.s0:sp.s1].clone()                       # what rank r would hold
+        rows = plan(local)
+        assert rows.shape[0] == sp.local_frames and torch_mod.equal(rows, whole[sp.f0:sp.f1])
+        ids = np.array([sp.f0, sp.f1 - 1])                    # global frames at the shard's edges vs the float64 definition
+        xs = np.stack([np.tile(x10, 2)[(g * hop) % x10.size:(g * hop) % x10.size + n] for g in ids])
+        truth = np.abs(np.fft.rfft(xs.astype(np.float64) * w.astype(np.float64), axis=1))
+        got = rows[torch_mod.tensor([0, sp.local_frames - 1], device=rows.device)].cpu().numpy()
+        assert nerr(got, truth).max() <= TOL_VS_TRUTH
+    del whole
+
+
 # --------------------------------------------- BASELINE configs[0]: the PCM16 stand-in --
 def test_config0_pcm16_stand_in(aa, oracle_mod, torch_mod, tmp_path):
     """BASELINE configs[0]: 1024-pt STFT, hop 256, Hann over `test_output.wav`.  The file is stripped
