@@ -492,7 +492,8 @@ int aa_sharded_pipeline(aa_comm *comm_in, aa_comm *comm_out, const float *full_d
                         aa_piece_fn compute, void *user, void *stream);
 /* aa_sharded_pipeline with aa_stft_execute_device of `plan` as the compute: rank `root`'s samples in, the dense
  * [total_frames][cols] slab on `root` out.  local_dev: the rank's sample range (capacity in floats), rows_dev its
- * [f1 - f0][cols] rows; on the root local_dev may be full_dev + s0 and rows_dev its slice of out_dev (no copies). */
+ * [f1 - f0][cols] rows; on the root local_dev may be full_dev + s0 and rows_dev its slice of out_dev (no copies).
+ * The plan, both communicators and `stream` belong to one device. */
 int aa_stft_execute_sharded(aa_stft_plan *plan, aa_comm *comm_in, aa_comm *comm_out, const float *full_dev,
                             int64_t n_samples, int32_t root, float *local_dev, int64_t local_capacity,
                             float *rows_dev, float *out_dev, int32_t n_pieces, void *stream);
