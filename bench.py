@@ -7,6 +7,9 @@ the fused kernel (frame + periodic Hann + 1024-pt real FFT + |X|, hop 256) over 
 48 kHz mono f32 (112 497 frames), input and output resident in HBM.  The JSON line also carries
   roofline      the kernel's algorithmic bytes (hop*4 in + 513*4 out = 3076 B/frame)
                 over its average launch duration (HIP events on the launch stream) against 8 TB/s;
+                `copy_ceiling`: what a plain device copy and the launch's 1 : 2 read : write mix of the
+                same byte count reach in this very run (the measured ceiling next to the nominal one);
+  sustained_*   >= 2 s of back-to-back launches of the same kernel between one pair of events;
   post_check    >= 64 rows of the slab the TIMED launches wrote, compared with the float64 truth
                 (first / last / ragged-tail / random rows); a failure exits non-zero;
   configs       the other BASELINE configurations that fit one GPU, each timed the same way:
@@ -22,7 +25,9 @@ N > 1 — BASELINE configs[3]: the 1 h / 172.8 M-sample / 674 997-frame corpus, 
 over the N ranks (strong scaling; one rank per GPU, launched by torch.distributed.run, or spawned
 from here when WORLD_SIZE is unset).  Every rank synthesises its own sample range.  `value` is
 (i) compute only, outputs stay sharded, no data-path collective; `e2e` is (ii) scatter of the
-samples from rank 0 + compute + gather of the rows to rank 0 over RCCL (grouped send/recv).
+samples from rank 0 + compute + gather of the rows to rank 0 over RCCL (grouped send/recv): the three
+legs one after the other (`serial_total_ms`) and overlapped - every rank's range in pieces, scatter
+k + 1 || compute k || gather k - 1 (`total_ms`); `e2e_cabi` the same on the C-ABI collectives.
 
 Rank 0 prints ONE JSON line (kept compact); the full record goes to gpurun_out/bench_detail_nN.json.
 """
