@@ -120,8 +120,9 @@ struct MelSched {
 // their quad, take the logs and write the 16-byte piece of the row: all 64 lanes busy for 8 quads.
 // Per-wave table: [kMelMfmaSteps][64][4] weights, then [2][64] dwords: the byte offset of the lane's
 // first piece in a power row, and the emission word of the lane as (quad slot = lane / 8, frame =
-// lane % 8): bits 0-4 slices of the quad (0: idle lane), 5-8 its first block, 9-13 the quad,
-// 24-28 the wave's largest slice count (the same in every lane).
+// lane % 8): bits 0-4 slices of the quad (0: idle lane), 5-8 its first block, 9-13 the quad, 14-15 the shift of
+// the second partial-sum set (below; the same in every lane), 24-28 the wave's largest slice count (the same in
+// every lane).
 constexpr int kMelMfmaSteps = 4;
 constexpr int kMelMfmaRowB = 528;                   // float offset of the wave's second power row in its scratch
 constexpr int kMelMfmaScratchDwords = 1072;         // scratch stride of these kinds: 268 float4 = 12 mod 16 -> the four

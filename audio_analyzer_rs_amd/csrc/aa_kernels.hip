@@ -1077,7 +1077,7 @@ void stft_wave1024_kernel(
 // latencies: 85.4 us against 77.2 (the exchanges' LDS round trip is then exposed at the chunk top, and the LDS-DMA has
 // half a chunk instead of a whole one to land: 82.7 us without any DMA).
 // LDS: [2][span] samples | 4 x kMelMfmaScratchDwords | kMfccM: the log-mel block [16][kMfccRowStride], the coefficient
-// tile [16][n_mfcc] | a zero float4 | the partial sums when a sample buffer is too small for them (hops below 147).
+// tile [16][n_mfcc] | a zero float4 | the partial sums when a sample buffer is too small for them (hops below 174).
 #ifndef AA_MELP_PRIO
 #define AA_MELP_PRIO 2103  // r4: 74.7 us against 78.8 with the rotation (log-mel), 84.8 against 91.0 (MFCC); 3210 75.5, 3103 / 3203 / 2102 within 0.5 % of 2103, 2113 / 2003 / 1003 lose 5 %
 #endif
