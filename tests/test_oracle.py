@@ -361,6 +361,58 @@ def test_wav_format_matches_recorder_semantics(tmp_path):
         '{"beat_position":2.250000,"raw_sample_offset":12,"velocity":1.0000}]')
 
 
+def test_wav_reader_other_sample_formats(tmp_path):
+    """f-4, the player's side: the reference plays files back through a general decoder (symphonia,
+    src/generators/player.rs:171-232); read_wav takes the linear WAV sample formats such a decoder accepts -
+    u8, s16, s24, s32, f32, f64, plain and WAVE_FORMAT_EXTENSIBLE headers, several channels, extra chunks, a
+    truncated last frame - with the decoder's scale factors (parity unpinned: symphonia is not in the tree)."""
+    import struct
+
+    import audio_analyzer_rs_amd as aa
+
+    def riff(fmt_body, payload, extra=b""):
+        chunks = b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + extra + b"data" + struct.pack("<I", len(payload)) + payload
+        return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+    def fmt_chunk(tag, ch, sr, bits, extensible=False):
+        align = ch * bits // 8
+        if not extensible:
+            return struct.pack("<HHIIHH", tag, ch, sr, sr * align, align, bits)
+        guid = struct.pack("<H", tag) + bytes.fromhex("000000001000800000aa00389b71")
+        return struct.pack("<HHIIHHHHI", 0xFFFE, ch, sr, sr * align, align, bits, 22, bits, 3) + guid
+
+    rng = np.random.default_rng(5)
+    n, sr = 257, 22050
+    cases = {
+        "u8": (1, 8, rng.integers(0, 256, (n, 2)).astype(np.uint8), lambda q: (q.astype(np.float32) - 128.0) / 128.0),
+        "s16": (1, 16, rng.integers(-32768, 32768, (n, 2)).astype("<i2"), lambda q: q.astype(np.float32) / 32768.0),
+        "s32": (1, 32, rng.integers(-2**31, 2**31, (n, 2)).astype("<i4"), lambda q: (q.astype(np.float64) / 2.0**31).astype(np.float32)),
+        "f32": (3, 32, rng.standard_normal((n, 2)).astype("<f4"), lambda q: q.astype(np.float32)),
+        "f64": (3, 64, rng.standard_normal((n, 2)).astype("<f8"), lambda q: q.astype(np.float32)),
+    }
+    for name, (tag, bits, q, want) in cases.items():
+        for ext in (False, True):
+            path = tmp_path / f"{name}_{int(ext)}.wav"
+            path.write_bytes(riff(fmt_chunk(tag, 2, sr, bits, ext), q.tobytes(), extra=b"LIST" + struct.pack("<I", 3) + b"abc\0"))
+            y, got_sr = aa.wav.read_wav(path)
+            assert got_sr == sr and y.dtype == np.float32 and y.shape == (n, 2), name
+            assert np.array_equal(y, want(q).astype(np.float32)), name
+    # 24-bit: three bytes per sample, sign extended; extremes and a mono file with a truncated last frame
+    q24 = np.array([0, 1, -1, 8388607, -8388608, 123456, -654321], dtype=np.int64)
+    b24 = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in q24)
+    (tmp_path / "s24.wav").write_bytes(riff(fmt_chunk(1, 1, 48000, 24), b24 + b"\x01\x02"))
+    y, got_sr = aa.wav.read_wav(tmp_path / "s24.wav")
+    assert got_sr == 48000 and y.shape == (7,) and np.array_equal(y, (q24.astype(np.float64) / 8388608.0).astype(np.float32))
+    assert y[3] < 1.0 and y[4] == -1.0
+    # refusals
+    (tmp_path / "alaw.wav").write_bytes(riff(fmt_chunk(6, 1, 8000, 8), b"\x00" * 16))
+    (tmp_path / "bad.wav").write_bytes(b"RIFX" + b"\x00" * 40)
+    (tmp_path / "nodata.wav").write_bytes(b"RIFF" + struct.pack("<I", 28) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt_chunk(1, 1, 8000, 16))
+    for bad in ("alaw.wav", "bad.wav", "nodata.wav"):
+        with pytest.raises(ValueError):
+            aa.wav.read_wav(tmp_path / bad)
+
+
 def test_detector_restatements_vs_golden(oracle_mod):
     """tests/golden/detectors_golden.npz (make_detector_golden.py) pins the "next"-row restatements:
     integer / flag outputs exactly, float recurrences exactly (plain f32 arithmetic), the
