@@ -382,6 +382,34 @@ def test_fused_mel_matches_truth_and_gemm_path(aa, oracle_mod, torch_mod, n, hop
     assert np.max(np.abs(fused - gemm)[near]) < 1e-3
 
 
+@pytest.mark.parametrize("n,hop", [(1024, 256), (2048, 512)])
+def test_mel_contraction_random_filterbanks(aa, oracle_mod, torch_mod, n, hop):
+    """The plan builder of the band-blocked contraction (quads, slices, window starts spread over the LDS bank
+    residues, per-wave shift of the second partial-sum set) over a seeded sweep of sample rates, band counts and band
+    edges - filterbanks with very narrow and very wide filters, few and many slices per quad.  Whatever the builder
+    decides (it falls back to the gather when a filterbank does not fit), every row matches the float64 definition."""
+    rng = np.random.default_rng(n)
+    tr = oracle_mod.truth
+    taken = {"mfma": 0, "gather": 0}
+    for case in range(28):
+        sr = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000, 96000]))
+        n_mels = int(rng.choice([16, 20, 24, 32, 40, 48, 64, 80, 96, 112, 128]))
+        fmin = float(rng.choice([0.0, 0.0, 20.0, 125.0, 300.0]))
+        fmax = float(rng.choice([0.0, 0.0, sr * 0.25, sr * 0.4, sr * 0.48]))
+        if fmax and fmax <= fmin + 200.0:
+            fmax = 0.0
+        plan = aa.Stft(n, hop, output="logmel", sample_rate=sr, n_mels=n_mels, fmin=fmin, fmax=fmax)
+        taken[plan.mel_path] += 1
+        x = aa.signals.synth_corpus(case, n + 122 * hop, sample_rate=sr, seed=1000 + case)
+        got = plan(torch_mod.from_numpy(x).cuda()).cpu().numpy()
+        P = np.abs(tr.stft_complex(x, n, hop, oracle_mod.hann_window(n))) ** 2
+        M = np.maximum(P @ tr.mel_filterbank(sr, n, n_mels, fmin, fmax or None).T, 1e-10)
+        assert got.shape == M.shape == (123, n_mels)
+        err = nerr(10.0 ** (got.astype(np.float64) / 10.0), M).max()
+        assert err < 2e-5, (case, sr, n_mels, fmin, fmax, plan.mel_path, err)
+    assert taken["mfma"] >= 14, taken          # the sweep exercises the contraction, not only its fallback
+
+
 def test_mel_path_names(aa):
     """aa_stft_mel_path_name: the reduction a plan takes follows from its parameters (include/aa_stft.h)."""
     mk = lambda n, hop, out, **kw: aa.Stft(n, hop, output=out, sample_rate=48000, **kw).mel_path
