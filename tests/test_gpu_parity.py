@@ -650,6 +650,38 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
         assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32))
 
 
+def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
+    """The five-wave form of the gates (below 256 streams, <= 192 bins) over bin counts around its wave boundaries and
+    frame counts around its 32-frame blocks - synthetic magnitudes with bursts, so that every branch of the floor
+    update and detected / fired / tick frames occur - bit for bit against the restatement, in one call and in two
+    pieces with the state carried, with a suppress mask."""
+    rng = np.random.default_rng(77)
+    for nb in (3, 33, 64, 65, 127, 128, 129, 191, 192):
+        for nf in (1, 2, 31, 32, 33, 63, 64, 65, 1000):
+            base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
+            bursts = rng.random(nf) < 0.08
+            base[bursts] *= (4.0 + 20.0 * rng.random((int(bursts.sum()), nb))).astype(np.float32)
+            mags = torch_mod.from_numpy(base).cuda()
+            flux, energy = aa.onset_flux(mags)
+            gf = (0.01 + 0.02 * rng.random(nf)).astype(np.float32)
+            sup = (rng.random(nf) < 0.1).astype(np.uint8)
+            gfd, supd = torch_mod.from_numpy(gf).cuda(), torch_mod.from_numpy(sup).cuda()
+            got, gstate = aa.onset_gates(mags, flux, energy, gfd, suppress=supd)
+            want, wstate, _ = oracle_mod.onset_gates(base, flux.cpu().numpy(), energy.cpu().numpy(), gf, suppress=sup)
+            for key in want:
+                assert np.array_equal(got[key].cpu().numpy(), want[key]), (nb, nf, key)
+            assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32)), (nb, nf)
+            if nf >= 33:
+                cut = int(rng.integers(1, nf))
+                o1, s1 = aa.onset_gates(mags[:cut].contiguous(), flux[:cut].contiguous(), energy[:cut].contiguous(),
+                                        gfd[:cut].contiguous(), suppress=supd[:cut].contiguous())
+                o2, s2 = aa.onset_gates(mags[cut:].contiguous(), flux[cut:].contiguous(), energy[cut:].contiguous(),
+                                        gfd[cut:].contiguous(), suppress=supd[cut:].contiguous(), state=s1)
+                for key in got:
+                    assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), got[key]), (nb, nf, cut, key)
+                assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), (nb, nf, cut)
+
+
 def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
     """The detectors are recurrences over one stream's frames; the batch entry points walk many
     streams (laid end to end, frame_offsets) in parallel - one wave / one lane per bin per stream.
