@@ -682,6 +682,29 @@ def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
                 assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), (nb, nf, cut)
 
 
+def test_tuner_floor_block_sizes(aa, oracle_mod, torch_mod):
+    """The tuner floor walks 32 frames per memory round trip (r4): bin counts around its wave width and frame counts
+    around the block length, one call and two pieces with the state carried - bit for bit against the restatement."""
+    rng = np.random.default_rng(78)
+    for nb in (1, 63, 64, 65, 257, 1025):
+        for nf in (1, 31, 32, 33, 64, 65, 500):
+            base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
+            loud = rng.random(nf) < 0.1
+            base[loud] *= (3.0 + 30.0 * rng.random((int(loud.sum()), nb))).astype(np.float32)
+            gf = (0.01 + 0.03 * rng.random(nf)).astype(np.float32)
+            mags, gfd = torch_mod.from_numpy(base).cuda(), torch_mod.from_numpy(gf).cuda()
+            eff, state = aa.tuner_floor(mags, gfd)
+            ref_eff, ref_state, _ = oracle_mod.tuner_floor(base, gf)
+            assert np.array_equal(eff.cpu().numpy(), ref_eff), (nb, nf)
+            assert np.array_equal(state.cpu().numpy().view(np.uint32), ref_state.view(np.uint32)), (nb, nf)
+            if nf >= 33:
+                cut = int(rng.integers(1, nf))
+                e1, s1 = aa.tuner_floor(mags[:cut].contiguous(), gfd[:cut].contiguous())
+                e2, s2 = aa.tuner_floor(mags[cut:].contiguous(), gfd[cut:].contiguous(), state=s1)
+                assert torch_mod.equal(torch_mod.cat([e1, e2]), eff), (nb, nf, cut)
+                assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32)), (nb, nf, cut)
+
+
 def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
     """The detectors are recurrences over one stream's frames; the batch entry points walk many
     streams (laid end to end, frame_offsets) in parallel - one wave / one lane per bin per stream.
