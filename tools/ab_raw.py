@@ -1,6 +1,6 @@
 """A/B of library builds through the bare C ABI (ctypes, four entry points), for builds older than the Python package's
 signature table: python tools/ab_raw.py <n_fft> <hop> <output code> libA.so libB.so ... [rounds]
-output codes: 0 complex, 1 mag, 2 power, 3 logpower (include/aa_stft.h).  One process per library and round, alternating."""
+output codes: 0 complex, 1 mag, 2 power, 3 logpower, 4 log-mel (128 bands), 5 MFCC (128 bands, 40 coefficients) (include/aa_stft.h).  One process per library and round, alternating."""
 import os, subprocess, sys
 
 CHILD = r"""
@@ -17,7 +17,7 @@ lib.aa_stft_plan_create.argtypes = [ctypes.POINTER(Cfg), ctypes.c_void_p, ctypes
 lib.aa_stft_execute_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
 lib.aa_stft_out_cols.argtypes = [ctypes.c_void_p]
 x = torch.from_numpy(signals.synth_corpus(0, 28_800_000)).cuda()
-cfg = Cfg(n_fft, hop, 0, kind, 48000, 0, 0, 0.0, 0.0, 0.0)
+cfg = Cfg(n_fft, hop, 0, kind, 48000, 128 if kind >= 4 else 0, 40 if kind == 5 else 0, 0.0, 0.0, 0.0)
 plan = ctypes.c_void_p()
 assert lib.aa_stft_plan_create(ctypes.byref(cfg), None, ctypes.byref(plan)) == 0
 nf = (x.numel() - n_fft) // hop + 1
