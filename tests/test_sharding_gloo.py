@@ -83,7 +83,7 @@ def _worker(rank, world, port, n_samples, n_fft, hop, tmpdir):
 
 
 @pytest.mark.parametrize("world,n_samples,n_fft,hop", [(2, 48_000, 1024, 256), (3, 20_011, 256, 64),
-                                                      (2, 1024 + 256, 1024, 256)])
+                                                      (2, 1024 + 256, 1024, 256), (8, 60_000, 1024, 256)])
 def test_sharded_job_matches_single_process(tmp_path, world, n_samples, n_fft, hop):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_samples, n_fft, hop, str(tmp_path)), nprocs=world, join=True)
