@@ -1565,6 +1565,8 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
 {
     if (!mags_dev || !flux_dev || !energy_dev || n_frames < 0 || n_bins < 2)
         return fail(AA_ERR_ARG, "aa_onset_flux_device: bad argument");
+    if (n_bins > 4160)
+        return fail(AA_ERR_UNSUPPORTED, "aa_onset_flux_device: n_bins > 4160 is not built (got %d)", n_bins);
     AA_HIP(aa::launch_onset_flux(mags_dev, prev_row_dev, flux_dev, energy_dev, n_frames, n_bins,
                                  (hipStream_t)stream));
     return AA_OK;
@@ -1586,6 +1588,36 @@ int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bin
                                   n_frames, n_bins, out_flux_dev, out_ema_dev, out_excess_dev, out_count_dev,
                                   out_flags_dev, out_velocity_dev, (hipStream_t)stream, nullptr, nullptr, 1,
                                   suppress_dev, calibrated));
+    return AA_OK;
+}
+
+// ------------------------------------------------------------------- diagnostics --
+int aa_diag_flux_div3_device(uint32_t first_bits, uint64_t count, uint64_t *mismatches_host)
+{
+    if (!mismatches_host || count > (1ull << 32))
+        return fail(AA_ERR_ARG, "aa_diag_flux_div3_device: bad argument");
+    unsigned long long *d = nullptr;
+    AA_HIP(hipMalloc(&d, sizeof *d));
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    if (e == hipSuccess)
+        e = aa::launch_flux_div3_check(first_bits, count, d, nullptr);
+    unsigned long long h = 0;
+    if (e == hipSuccess)
+        e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(AA_ERR_HIP, "aa_diag_flux_div3_device: %s", hipGetErrorString(e));
+    *mismatches_host = h;
+    return AA_OK;
+}
+
+int aa_diag_stream_copy_device(const float *src_dev, float *dst_dev, int64_t n_floats, int32_t writes_per_read,
+                               void *stream)
+{
+    if (!src_dev || !dst_dev || n_floats < 0 || (n_floats & 3) || writes_per_read < 1 || writes_per_read > 2 ||
+        ((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst_dev)) & 15u))
+        return fail(AA_ERR_ARG, "aa_diag_stream_copy_device: n_floats %% 4 == 0, 16-byte aligned buffers, 1 or 2 writes per read");
+    AA_HIP(aa::launch_stream_copy(src_dev, dst_dev, n_floats, writes_per_read, (hipStream_t)stream));
     return AA_OK;
 }
 
@@ -1623,6 +1655,8 @@ int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offse
     if (!mags_dev || !frame_offsets_dev || !flux_dev || !energy_dev || n_streams < 1 || n_frames_total < 0 ||
         n_bins < 2)
         return fail(AA_ERR_ARG, "aa_onset_flux_batch_device: bad argument");
+    if (n_bins > 4160)
+        return fail(AA_ERR_UNSUPPORTED, "aa_onset_flux_batch_device: n_bins > 4160 is not built (got %d)", n_bins);
     AA_HIP(aa::launch_onset_flux(mags_dev, prev_rows_dev, flux_dev, energy_dev, n_frames_total, n_bins,
                                  (hipStream_t)stream, frame_offsets_dev, n_streams));
     return AA_OK;

@@ -273,5 +273,9 @@ hipError_t launch_tuner_floor(const float *mags, const float *global_floor, floa
                               const int32_t *init_flags = nullptr, int n_streams = 1);
 hipError_t launch_downmix(const float *in, float *out, int64_t n_frames, int channels,
                           hipStream_t stream);
+// diagnostics: the flux kernel's x / 3 against the IEEE division over `n` consecutive bit patterns; a plain /
+// twice-stored nontemporal copy of n_floats floats (n_floats % 4 == 0, 16-byte aligned buffers)
+hipError_t launch_flux_div3_check(uint32_t first, uint64_t n, unsigned long long *mismatches_dev, hipStream_t stream);
+hipError_t launch_stream_copy(const float *src, float *dst, int64_t n_floats, int writes, hipStream_t stream);
 
 }  // namespace aa

@@ -126,54 +126,265 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float *__rest
 
 // Onset front end (src/analysis/onset.rs:261-291), first of the "next" rows after the STFT:
 // per frame the 3-bin-smoothed, frequency-weighted positive spectral flux against the previous
-// frame's magnitudes and the frame energy.  One wave per frame; the reference's running f32
-// sums become wave reductions (different summation order: tolerance, not bit-exact).
-// offsets (nullable): frame_offsets[n_streams + 1] of concatenated streams; the first frame of a
-// stream takes prev0 + s * n_bins (or zeros) as its previous row instead of the row before it.
-__global__ __launch_bounds__(256) void onset_flux_kernel(const float *__restrict__ mags,
-                                                         const float *__restrict__ prev0,
-                                                         float *__restrict__ flux,
-                                                         float *__restrict__ energy, int64_t n_frames,
-                                                         int n_bins, const int64_t *__restrict__ offsets,
-                                                         int n_streams)
+// frame's magnitudes and the frame energy.
+// r5: ONE LANE PER FRAME, walking the bins in order - the reference's own sequential f32 sums (fp contract off, IEEE
+// division by 3, the weight 1 - i / n evaluated once per bin with the reference's expression), so flux and energy are
+// BIT-IDENTICAL to the CPU restatement; rounds 1-4 ran one wave per frame (a tree sum: 1e-5, four dependent dword loads
+// per element, a binary search over the stream offsets per frame and lane: 348 us for the 450 k frames of ten minutes).
+// A wave takes blocks of 64 consecutive frames: the 65 rows a block needs (its own and the one before it) are ONE
+// contiguous span of the spectrogram, fetched as coalesced 16-byte pieces into registers - the next block's while the
+// current one is walked - and handed over through LDS, where lane t walks row t at an odd stride (n_bins = n_fft/2 + 1:
+// conflict free).  Every element leaves HBM once.  Spectra wider than 129 bins (the onset geometry) go through LDS in
+// column tiles of 126 bins with the same accumulators (kFluxFlat = false).
+// offsets (nullable): frame_offsets[n_streams + 1] of concatenated streams; the first frame of a stream takes
+// prev0 + s * n_bins (or zeros) as its previous row.  The stream of a block's first frame is found ONCE per block by a
+// 64-ary search across the lanes, the starts inside the block are scattered into an LDS row (ds_max: of several empty
+// streams that start on one frame the last one owns it).
+constexpr int kFluxT = 64;                          // frames per block: one per lane
+constexpr int kFluxV4 = 33;                         // 16-byte pieces per lane of a flat span: 65 * 129 + 3 floats
+constexpr int kFluxCh = 16;                         // bins per batch of LDS reads (a lone wave must not wait per bin)
+constexpr int kFluxTileBins = 7 * kFluxCh;          // interior bins per column tile: chunk starts stay 1 mod 16
+constexpr int kFluxTileStride = kFluxTileBins + 3;  // bins kb .. kb + 113 (+ 1: odd stride), 115 floats per row
+// x / 3.0f, correctly rounded, in four instructions instead of the ten of the IEEE division sequence: q0 = x * RN(1/3),
+// the exact remainder x - 3 q0 by one FMA, one FMA to correct, and the division's own last step, v_div_fixup_f32, for the
+// three inputs the remainder cannot serve (+-inf: its remainder is NaN; -0: the add loses the sign).  Equal to the
+// division for EVERY f32 bit pattern: tests/test_oracle.py::test_div3_core_is_the_division runs all 2^32 through the C
+// copy of the three-operation core (exactly those three differ), tests/test_gpu_parity.py::test_flux_div3_exhaustive all
+// 2^32 through this function on the device.
+__device__ __forceinline__ float flux_div3(float x)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t t = wave0; t < n_frames; t += nwaves) {
-        const float *m = mags + t * n_bins;
-        const float *pv = m - n_bins;
-        if (offsets) {
-            int lo = 0, hi = n_streams;              // last stream whose first frame is <= t
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (offsets[mid] <= t)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            if (offsets[lo] == t)
-                pv = prev0 ? prev0 + (int64_t)lo * n_bins : nullptr;
-        } else if (t == 0) {
-            pv = prev0;
-        }
-        float fl = 0.0f, en = 0.0f;
-        for (int i = lane; i < n_bins; i += 64) {
-            const float mag = m[i];
-            en += mag;
-            const float sm = (i == 0 || i >= n_bins - 1) ? mag : (m[i - 1] + mag + m[i + 1]) / 3.0f;
-            // the reference forms weight = 1.0 - (i as f32 / half_size as f32): same expression
-            const float weight = 1.0f - (float)i / (float)n_bins;
-            const float diff = sm - (pv ? pv[i] : 0.0f);
-            if (diff > 0.0f)
-                fl += diff * weight;
-        }
+    const float r = 0x1.555556p-2f;
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-3.0f, q0, x);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r, q0), 3.0f, x);
+}
+__global__ void flux_div3_check_kernel(uint32_t first, uint64_t n, unsigned long long *mismatches)
+{
+#pragma clang fp contract(off)
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first + (uint32_t)i);
+        const float a = flux_div3(x), b = x / 3.0f;
+        bad += (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) ? 1 : 0;
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+// The bins [k0, k1) of one tile, in order, for this lane's frame: bin i at cur[i - kb], the frame before it at prv[i - kb]
+// (first: the frame starts a stream - its previous row is p0, or zeros).  Bins 0 and n_bins - 1 are not smoothed
+// (onset.rs:264-268); the interior bins run in batches of 16 whose LDS reads are all issued up front at immediate
+// offsets - no branch and no wait inside a batch.  Batches start at bins 1 mod 16 (their weights: aligned float4s).
+template <bool ANYFIRST>
+__device__ __forceinline__ void flux_walk(const float *cur, const float *prv, bool first, const float *p0,
+                                          const float *wsh, int kb, int k0, int k1, int n_bins, float &fl, float &en)
+{
+#pragma clang fp contract(off)
+    const int last = n_bins - 1;
+    const float *pq = (ANYFIRST && first) ? cur : prv;           // (a stream's first frame has no row before it in the tile)
+    auto prev_of = [&](int i) {
+        if (!ANYFIRST)
+            return prv[i - kb];
+        const float own = (first && p0) ? p0[i] : 0.0f;
+        return first ? own : pq[i - kb];
+    };
+    auto end_bin = [&](int i) {                                  // an end bin: the magnitude itself
+        const float m = cur[i - kb];
+        en += m;
+        fl += fmaxf(m - prev_of(i), 0.0f) * (i == 0 ? 1.0f : wsh[i - 1]);
+    };
+    if (k0 == 0)
+        end_bin(0);
+    const int i_lo = k0 > 1 ? k0 : 1, i_hi = k1 < last ? k1 : last;
+    if (i_lo < i_hi) {
+        float m_lo = cur[i_lo - 1 - kb], m_i = cur[i_lo - kb];
+        float c[kFluxCh], pv[kFluxCh];
+        v4f w[kFluxCh / 4];
+        auto step = [&](int j) {
+            const float m_hi = c[j];
+            en += m_i;
+            const float sm = flux_div3(m_lo + m_i + m_hi);
+            fl += fmaxf(sm - pv[j], 0.0f) * w[j >> 2][j & 3];
+            m_lo = m_i;
+            m_i = m_hi;
+        };
+        int i = i_lo;
+        for (; i + kFluxCh <= i_hi; i += kFluxCh) {
+            const float *cp = cur + (i + 1 - kb), *pp = pq + (i - kb);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            fl += __shfl_xor(fl, off);
-            en += __shfl_xor(en, off);
+            for (int j = 0; j < kFluxCh; ++j)
+                c[j] = cp[j];
+#pragma unroll
+            for (int j = 0; j < kFluxCh; ++j) {
+                if (ANYFIRST) {
+                    const float own = (first && p0) ? p0[i + j] : 0.0f;
+                    pv[j] = first ? own : pp[j];
+                } else {
+                    pv[j] = pp[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kFluxCh / 4; ++j)
+                w[j] = *reinterpret_cast<const v4f *>(wsh + i - 1 + 4 * j);
+#pragma unroll
+            for (int j = 0; j < kFluxCh; ++j)
+                step(j);
         }
-        if (lane == 0) {
+        if (i < i_hi) {                                          // the last, short batch: reads past it stay in the row
+            const int cnt = i_hi - i;
+#pragma unroll
+            for (int j = 0; j < kFluxCh; ++j) {
+                const int ic = i + 1 + j < last ? i + 1 + j : last, ip = i + j < last ? i + j : last;
+                c[j] = cur[ic - kb];
+                pv[j] = prev_of(ip);
+            }
+#pragma unroll
+            for (int j = 0; j < kFluxCh / 4; ++j)
+                w[j] = *reinterpret_cast<const v4f *>(wsh + i - 1 + 4 * j);
+#pragma unroll
+            for (int j = 0; j < kFluxCh; ++j)
+                if (j < cnt)
+                    step(j);
+        }
+    }
+    if (k1 == n_bins && last > 0)
+        end_bin(last);
+}
+template <bool FLAT>
+__global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict__ mags,
+                                                        const float *__restrict__ prev0,
+                                                        float *__restrict__ flux,
+                                                        float *__restrict__ energy, int64_t n_frames,
+                                                        int n_bins, const int64_t *__restrict__ offsets,
+                                                        int n_streams)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float flux_lds[];
+    const int lane = threadIdx.x;
+    float *tile = flux_lds;
+    // wsh[q] = the reference's weight of bin q + 1 (chunks start at bins 1 mod 16: their weights are aligned float4s),
+    // w of bin 0 is 1 - 0 / n = 1 exactly
+    float *wsh = tile + (FLAT ? 4 * 64 * kFluxV4 : (kFluxT + 1) * kFluxTileStride + 1);
+    const int wsh_len = ((n_bins + 3) & ~3) + kFluxCh;
+    int *starts = reinterpret_cast<int *>(wsh + wsh_len);       // [64] stream that starts at the block's frame (+ 1)
+    for (int q = lane; q < wsh_len; q += 64)
+        wsh[q] = q + 1 < n_bins ? 1.0f - ((float)(q + 1) / (float)n_bins) : 0.0f;
+    const int64_t n_blocks = (n_frames + kFluxT - 1) / kFluxT;
+    const uintptr_t mags_addr = reinterpret_cast<uintptr_t>(mags);
+
+    // ---- the flat span of a block: floats [s0, s1) of the spectrogram, fetched from the 16-byte boundary below s0.
+    // Pieces that lie inside the span are 16-byte loads; the (at most two) pieces that straddle an end of it are
+    // fetched float by float by lanes 0-3 (nothing outside the caller's rows is ever read) ----
+    v4f regs[FLAT ? kFluxV4 : 1];
+    float edge_head = 0.0f, edge_tail = 0.0f;
+    auto span_of = [&](int64_t b, int64_t &s0, int64_t &n, int &lead) {
+        const int64_t t0 = b * kFluxT;
+        s0 = (t0 > 0 ? t0 - 1 : 0) * n_bins;
+        const int64_t te = t0 + kFluxT < n_frames ? t0 + kFluxT : n_frames;
+        n = te * n_bins - s0;
+        lead = (int)(((mags_addr + 4u * (uint64_t)s0) & 15u) >> 2);
+    };
+    auto fetch_flat = [&](int64_t b) {
+        int64_t s0, n;
+        int lead;
+        span_of(b, s0, n, lead);
+        const float *base = mags + s0 - lead;                    // 16-byte aligned
+#pragma unroll
+        for (int u = 0; u < kFluxV4; ++u) {
+            const int64_t j = 4 * (int64_t)(lane + 64 * u) - lead;   // first float of the piece, relative to s0
+            regs[u] = (j >= 0 && j + 4 <= n) ? *reinterpret_cast<const v4f *>(base + 4 * (lane + 64 * u)) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        const int64_t jh = lane - lead, jt = ((lead + n) & ~(int64_t)3) - lead + lane;
+        edge_head = (lane < 4 && jh >= 0 && jh < n) ? mags[s0 + jh] : 0.0f;
+        edge_tail = (lane < 4 && jt >= 0 && jt < n) ? mags[s0 + jt] : 0.0f;
+    };
+    if (FLAT && (int64_t)blockIdx.x < n_blocks)
+        fetch_flat(blockIdx.x);
+
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t t0 = b * kFluxT, t = t0 + lane;
+        const bool live = t < n_frames;
+        __syncthreads();                                         // (one wave: orders the LDS accesses of two blocks)
+        int64_t s0, n;
+        int lead;
+        span_of(b, s0, n, lead);
+        if (FLAT) {
+#pragma unroll
+            for (int u = 0; u < kFluxV4; ++u)
+                reinterpret_cast<v4f *>(tile)[lane + 64 * u] = regs[u];
+            __syncthreads();
+            const int pt = (int)((lead + n) >> 2);               // the piece that holds the span's last floats
+            if (lane < 4 && lane >= lead && lane - lead < n)
+                tile[lane] = edge_head;
+            if (lane < 4 && ((lead + n) & 3) != 0 && lane < (int)((lead + n) & 3) && 4 * pt + lane >= lead)
+                tile[4 * pt + lane] = edge_tail;
+        }
+        starts[lane] = 0;
+        __syncthreads();
+        if (FLAT && b + gridDim.x < n_blocks)
+            fetch_flat(b + gridDim.x);                           // in flight while this block is walked
+
+        // ---- which lanes start a stream, and which one ----
+        bool first = false;
+        const float *p0 = nullptr;
+        if (offsets) {
+            int lo = 0, hi = n_streams;                          // the last stream with offsets[s] <= t0 is in [lo, hi)
+            while (hi - lo > 1) {
+                const int step = (hi - lo + 63) >> 6;
+                const int idx = lo + lane * step;
+                const bool le = idx < hi && offsets[idx] <= t0;
+                const int c = __popcll(__ballot(le));            // monotone: a prefix of the lanes (lane 0 always)
+                const int nlo = lo + (c - 1) * step;
+                hi = lo + c * step < hi ? lo + c * step : hi;
+                lo = nlo;
+            }
+            for (int s = lo; s < n_streams; s += 64) {           // the starts inside the block, 64 streams at a time
+                const int idx = s + lane;
+                const int64_t o = idx < n_streams ? offsets[idx] : INT64_MAX;
+                if (o >= t0 && o < t0 + kFluxT)
+                    atomicMax(&starts[(int)(o - t0)], idx + 1);
+                if (__ballot(o >= t0 + kFluxT) != 0)
+                    break;
+            }
+            __syncthreads();
+            const int sf = starts[lane];
+            first = sf != 0 || t == 0;
+            p0 = (first && prev0) ? prev0 + (int64_t)(sf - 1) * n_bins : nullptr;
+        } else {
+            first = t == 0;
+            p0 = first ? prev0 : nullptr;
+        }
+        const bool any_first = __ballot(first && live) != 0;
+
+        float fl = 0.0f, en = 0.0f;
+        auto walk = [&](const float *cur, const float *prv, int kb, int k0, int k1) {
+            if (any_first)
+                flux_walk<true>(cur, prv, first, p0, wsh, kb, k0, k1, n_bins, fl, en);
+            else
+                flux_walk<false>(cur, prv, first, p0, wsh, kb, k0, k1, n_bins, fl, en);
+        };
+        if (FLAT) {
+            // float j of the span sits at tile[lead + j]; row r of the block (r = 0: the frame before it) starts n_bins
+            // floats further on - except in block 0, whose span has no such row
+            const float *row0 = tile + lead - (t0 > 0 ? 0 : n_bins);
+            walk(row0 + (lane + 1) * n_bins, row0 + lane * n_bins, 0, 0, n_bins);
+        } else {
+            for (int kb = 0; kb == 0 || kb + 1 < n_bins; kb += kFluxTileBins) {
+                // column c of the tile holds bin kb + c; the tile walks bins [kb + 1, kb + 113) (the first one bin 0 too)
+                const int k0 = kb ? kb + 1 : 0, k1 = kb + 1 + kFluxTileBins < n_bins ? kb + 1 + kFluxTileBins : n_bins;
+                __syncthreads();
+                for (int r = 0; r <= kFluxT; ++r) {
+                    const int64_t f = t0 - 1 + r;
+#pragma unroll
+                    for (int c = lane; c < kFluxTileBins + 2; c += 64) {
+                        const int k = kb + c;
+                        tile[r * kFluxTileStride + c] = (f >= 0 && f < n_frames && k < n_bins) ? mags[f * n_bins + k] : 0.0f;
+                    }
+                }
+                __syncthreads();
+                walk(tile + (lane + 1) * kFluxTileStride, tile + lane * kFluxTileStride, kb, k0, k1);
+            }
+        }
+        if (live) {
             flux[t] = fl;
             energy[t] = en;
         }
@@ -236,9 +447,11 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         out_velocity += f0;
         if (suppress)
             suppress += f0;
-        state += (int64_t)blockIdx.x * (n_bins + 3);
+        state += (int64_t)blockIdx.x * (n_bins + 4);
         initialized = init_flags ? init_flags[blockIdx.x] : 0;
     }
+    if (n_frames <= 0)
+        return;                                      // (nothing seen: the state stays as it was, and uninitialised)
     float *blk = gate_lds;                           // frames_per_block rows of magnitudes (+ one pad row)
     const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
     const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
@@ -251,13 +464,16 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         fl[j] = valid[j] ? state[64 * j + lane] : 1.0f;
     }
     float ema = 0.0f, thr = 0.0f;
-    int since = 4;
+    int since = 4, cal_done = 0;
     bool init = initialized != 0;
     if (init) {
         ema = state[n_bins];
         thr = state[n_bins + 1];
         since = __float_as_int(state[n_bins + 2]);
+        cal_done = __float_as_int(state[n_bins + 3]);
     }
+    if (calibrated != 2)
+        cal_done = calibrated == 1;
     const int block_floats = frames_per_block * n_bins;
     const int64_t n_blocks = (n_frames + frames_per_block - 1) / frames_per_block;
     float nxt[kGatePrefetchRegs];
@@ -287,7 +503,7 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         const bool mine = lane < nfb;
         const float in_flux = mine ? flux[t0 + lane] : 0.0f, in_energy = mine ? energy[t0 + lane] : 0.0f;
         const float in_gf = mine ? global_floor[t0 + lane] : 0.0f;
-        const int in_sup = (mine && suppress) ? (int)suppress[t0 + lane] : 0;
+        const int in_sup = (mine && suppress) ? (int)suppress[t0 + lane] : (calibrated == 2 ? 2 : 0);
         float o_flux = 0.0f, o_ema = 0.0f, o_exc = 0.0f, o_vel = 0.0f;
         int o_count = 0, o_flags = 0;
         // this frame's magnitudes; the next frame's are read from LDS one iteration ahead
@@ -343,13 +559,21 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
             const bool burst_onset = mx > 3.0f && count >= 3;
             const bool detected = flux_onset && burst_onset;
             const bool rising = frame_energy > ema * 1.5f;
-            // onset.rs:393-440: a detected onset inside the metronome's tick guard is dropped, and before the latency
-            // calibration has completed nothing fires (both supplied by the caller: they depend on the transport)
-            const bool tick = detected && __builtin_amdgcn_readlane(in_sup, i) != 0;
-            const bool fired = detected && !tick && rising && since >= 3 && calibrated != 0;
+            // onset.rs:361-371, 393-440: the transport's share of the decision, supplied by the caller as a per-frame
+            // mask (bit 0 tick guard, bit 1 calibration click played and the residual plausible, bit 2 calibration timed
+            // out) and the calibration mode; a gated onset fires once the calibration is done, or completes it (mode 2)
+            const int mk = __builtin_amdgcn_readlane(in_sup, i);
+            if (calibrated == 2 && (mk & 4))
+                cal_done = 1;
+            const bool tick = detected && (mk & 1) != 0;
+            const bool gated = detected && !tick && rising && since >= 3;
+            const bool fired = gated && cal_done != 0;
+            const bool consumed = gated && cal_done == 0 && calibrated == 2 && (mk & 2) != 0;
+            if (consumed)
+                cal_done = 1;
             float vel = fmaxf(current_flux, mx * 5.0f) / 50.0f;
             vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
-            if (fired || (detected && since < 3))
+            if (fired || consumed || (detected && since < 3))
                 since = 0;
             else if (since < 0x7fffffff)
                 since += 1;
@@ -360,7 +584,7 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
                 o_vel = vel;
                 o_count = count;
                 o_flags = (int)flux_onset | ((int)burst_onset << 1) | ((int)detected << 2) | ((int)rising << 3) |
-                          ((int)fired << 4) | ((int)tick << 5);
+                          ((int)fired << 4) | ((int)tick << 5) | ((int)gated << 6) | ((int)consumed << 7);
             }
 #pragma unroll
             for (int j = 0; j < BPL; ++j)
@@ -383,6 +607,7 @@ __global__ __launch_bounds__(64) void onset_gates_kernel(
         state[n_bins] = ema;
         state[n_bins + 1] = thr;
         state[n_bins + 2] = __int_as_float(since);
+        state[n_bins + 3] = __int_as_float(cal_done);
     }
 }
 
@@ -450,9 +675,11 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         out_velocity += f0;
         if (suppress)
             suppress += f0;
-        state += (int64_t)blockIdx.x * (n_bins + 3);
+        state += (int64_t)blockIdx.x * (n_bins + 4);
         initialized = init_flags ? init_flags[blockIdx.x] : 0;
     }
+    if (n_frames <= 0)
+        return;                                      // (nothing seen: the state stays as it was, and uninitialised)
     // rows of the ratio image: n_bins columns + a spare one the lanes without a bin write to (no per-frame lane
     // masks), an odd stride (the column walk of the R wave is bank-conflict free)
     const int stride = (n_bins + 1) | 1;
@@ -525,17 +752,20 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         const bool in = lane < kGateT && t < n_frames;
         vf = in ? flux[t] : 0.0f;
         ve = in ? energy[t] : 0.0f;
-        vs = (in && suppress) ? (int)suppress[t] : 0;
+        vs = (in && suppress) ? (int)suppress[t] : (calibrated == 2 ? 2 : 0);
     };
     // B: lanes 0-31 carry the energy EMA, lanes 32-63 the flux threshold (the same instruction stream for both)
     const int grp = lane >> 5;
     float chain_s = 0.0f;
     const float k_rise = grp ? rise_memory : ENERGY_EMA_RISE, k_decay = grp ? decay_memory : ENERGY_EMA_DECAY;
-    int since = 4;
+    int since = 4, cal_done = 0;
     if (initialized) {
         chain_s = grp ? state[n_bins + 1] : state[n_bins];
         since = __builtin_amdgcn_readfirstlane(__float_as_int(state[n_bins + 2]));
+        cal_done = __builtin_amdgcn_readfirstlane(__float_as_int(state[n_bins + 3]));
     }
+    if (calibrated != 2)
+        cal_done = calibrated == 1;
     if (role < 3 && n_blocks > 0) {
         fetch(0, cur, cur_gf);
         if (!initialized)                            // onset.rs:304-309: the floors start at the first frame's magnitudes
@@ -701,30 +931,46 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 const bool flux_onset = mine && is_onset && v_flux > thr_i * multiplier;
                 const bool detected = flux_onset && bo;
                 const bool rising = v_energy > ema_i * 1.5f;
-                const bool tick = detected && v_sup != 0;
-                const bool armed = detected && !tick && rising && calibrated != 0;       // fires if >= 3 frames since the last one
-                // frames since the last onset: + 1 per frame, except at a detected frame (0 when it fires or comes
-                // within 3 frames of the last one) - stepped over the set bits of the block's detection mask
+                // the transport's share (onset.rs:361-371, 393-440), a per-frame mask: bit 0 tick guard, bit 1 calibration
+                // click played and the residual plausible, bit 2 calibration timed out
+                const bool tick = detected && (v_sup & 1) != 0;
+                const bool armed = detected && !tick && rising;          // gated if >= 3 frames since the last onset
+                // frames since the last onset: + 1 per frame, except at a detected frame (0 when it fires, completes the
+                // calibration or comes within 3 frames of the last one) - stepped over the set bits of the block's
+                // detection mask; the calibration (mode 2) is done from the first timed-out frame on, or from the
+                // first gated frame whose residual is plausible, which it consumes
                 const uint64_t det_mask = __ballot(detected), arm_mask = __ballot(armed);
-                uint64_t fired_mask = 0, todo = det_mask;
+                const uint64_t open_mask = __ballot(mine && calibrated == 2 && (v_sup & 2) != 0);
+                const uint64_t tmo_mask = __ballot(mine && calibrated == 2 && (v_sup & 4) != 0);
+                const int tmo_at = tmo_mask ? __builtin_ctzll(tmo_mask) : 64;
+                uint64_t fired_mask = 0, gated_mask = 0, used_mask = 0, todo = det_mask;
                 int at = 0;                                             // frames of the block already counted
                 auto advance = [&](int n) { since = since > 0x7fffffff - n ? 0x7fffffff : since + n; };
                 while (todo) {
                     const int i = __builtin_ctzll(todo);
                     todo &= todo - 1;
                     advance(i - at);
-                    const bool f = ((arm_mask >> i) & 1) != 0 && since >= 3;
+                    const bool g = ((arm_mask >> i) & 1) != 0 && since >= 3;
+                    const bool done = cal_done != 0 || i >= tmo_at;
+                    const bool f = g && done, u = g && !done && ((open_mask >> i) & 1) != 0;
+                    gated_mask |= (uint64_t)g << i;
                     fired_mask |= (uint64_t)f << i;
-                    if (f || since < 3)
+                    used_mask |= (uint64_t)u << i;
+                    if (u)
+                        cal_done = 1;
+                    if (f || u || since < 3)
                         since = 0;
                     else
                         advance(1);
                     at = i + 1;
                 }
                 advance(nfb - at);
-                const bool fired = ((fired_mask >> lane) & 1) != 0;
+                if (tmo_at < 64)
+                    cal_done = 1;
+                const bool fired = ((fired_mask >> lane) & 1) != 0, gated = ((gated_mask >> lane) & 1) != 0;
+                const bool used = ((used_mask >> lane) & 1) != 0;
                 const int fl_bits = (int)flux_onset | ((int)bo << 1) | ((int)detected << 2) | ((int)rising << 3) |
-                                    ((int)fired << 4) | ((int)tick << 5);
+                                    ((int)fired << 4) | ((int)tick << 5) | ((int)gated << 6) | ((int)used << 7);
                 if (mine) {
                     out_flux[t0 + lane] = v_flux;
                     out_ema[t0 + lane] = ema_i;
@@ -747,8 +993,10 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
             state[n_bins] = chain_s;
         if (lane == 32)
             state[n_bins + 1] = chain_s;
-        if (lane == 0)
+        if (lane == 0) {
             state[n_bins + 2] = __int_as_float(since);
+            state[n_bins + 3] = __int_as_float(cal_done);
+        }
     }
 }
 
@@ -1096,7 +1344,56 @@ __global__ void downmix_stereo4_kernel(const dm4 *__restrict__ in, dm4 *__restri
     }
 }
 
+// Diagnostics (include/aa_stft.h, aa_diag_stream_copy_device): the memory system's own ceiling for a launch's byte count,
+// measured with the product's access idiom and NO arithmetic - 16-byte nontemporal loads and stores, persistent
+// workgroups on contiguous runs.  WRITES = 1: a plain copy; WRITES = 2: every piece stored twice (dst[i], dst[n + i]),
+// the 1 : 2 read : write mix of the magnitude launch (hop floats in, ~2 hop floats out per frame).
+template <int WRITES>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4)
+{
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < n4 ? i0 + per : n4;
+    int64_t i = i0 + threadIdx.x;
+    for (; i + 3 * 256 < i1; i += 4 * 256) {
+        v4f r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            r[u] = __builtin_nontemporal_load(src + i + 256 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __builtin_nontemporal_store(r[u], dst + i + 256 * u);
+            if (WRITES == 2)
+                __builtin_nontemporal_store(r[u], dst + n4 + i + 256 * u);
+        }
+    }
+    for (; i < i1; i += 256) {
+        const v4f r = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(r, dst + i);
+        if (WRITES == 2)
+            __builtin_nontemporal_store(r, dst + n4 + i);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_stream_copy(const float *src, float *dst, int64_t n_floats, int writes, hipStream_t stream)
+{
+    if (n_floats <= 0)
+        return hipSuccess;
+    if ((n_floats & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) || writes < 1 || writes > 2)
+        return hipErrorInvalidValue;
+    const int64_t n4 = n_floats / 4;
+    int64_t blocks = (n4 + 1023) / 1024;
+    if (blocks > 2048)
+        blocks = 2048;                               // eight workgroups per CU
+    if (writes == 1)
+        hipLaunchKernelGGL(stream_copy_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4);
+    else
+        hipLaunchKernelGGL(stream_copy_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4);
+    return hipGetLastError();
+}
 
 hipError_t launch_rows_gemm(bool take_log, const float *A, int lda, const float *B, const int *tile_k,
                             float *C, int64_t n_rows, int K, int n_cols, int n_pad, float log_floor,
@@ -1123,11 +1420,39 @@ hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux,
 {
     if (n_frames <= 0)
         return hipSuccess;
-    int64_t blocks = (n_frames + 3) / 4;
-    if (blocks > 8192)
-        blocks = 8192;
-    hipLaunchKernelGGL(onset_flux_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mags, prev0, flux,
-                       energy, n_frames, n_bins, offsets, n_streams);
+    const int64_t n_blocks = (n_frames + kFluxT - 1) / kFluxT;
+    // the flat form holds a block's 65 rows (+ 3 floats of alignment) in 33 sixteen-byte pieces per lane
+    const bool flat = (int64_t)(kFluxT + 1) * n_bins + 3 <= 4 * 64 * kFluxV4;
+    const size_t lds = sizeof(float) * (size_t)((flat ? 4 * 64 * kFluxV4 : (kFluxT + 1) * kFluxTileStride + 1) + ((n_bins + 3) & ~3) + kFluxCh + 64);
+    if (lds > 64 * 1024)
+        return hipErrorInvalidValue;
+    // persistent waves, one per workgroup: four fit a CU's LDS (34 KB each), blocks dealt round robin
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0)
+            cus = 256;
+    }
+    int64_t blocks = (int64_t)cus * 4;
+    if (blocks > n_blocks)
+        blocks = n_blocks;
+    if (flat)
+        hipLaunchKernelGGL(onset_flux_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, stream, mags, prev0, flux,
+                           energy, n_frames, n_bins, offsets, n_streams);
+    else
+        hipLaunchKernelGGL(onset_flux_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, stream, mags, prev0, flux,
+                           energy, n_frames, n_bins, offsets, n_streams);
+    return hipGetLastError();
+}
+
+hipError_t launch_flux_div3_check(uint32_t first, uint64_t n, unsigned long long *mismatches_dev, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(flux_div3_check_kernel, dim3(4096), dim3(256), 0, stream, first, n, mismatches_dev);
     return hipGetLastError();
 }
 
@@ -1142,9 +1467,11 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
         return hipSuccess;
     if (n_bins < 1 || n_bins > 64 * kGatePrefetchRegs)
         return hipErrorInvalidValue;
-    // few streams of the onset geometry: the recurrences taken apart, one workgroup of five waves per stream (a single
-    // ten-minute stream: 313 -> ~30 ms); many streams already fill the chip with one wave each
-    if (n_bins <= 192 && n_streams < 256) {
+    // the onset geometry: the recurrences taken apart, one workgroup of five waves per stream (a single ten-minute
+    // stream: 313 -> ~30 ms).  r5: at every stream count - rounds 1-4 went back to one wave per stream from 256 streams
+    // on, i.e. 1024 streams were 1024 lone waves walking 440 frames at 0.7 us each (351 us); four of these workgroups
+    // fit a CU, so 1024 streams are resident at once with five waves per SIMD to issue from
+    if (n_bins <= 192) {
         const int stride = (n_bins + 1) | 1;
         const size_t lds2 = sizeof(float) * (size_t)(kGateOpsDwords + 2 * kGateT * stride + 4 * kGateT);
         hipLaunchKernelGGL(onset_gates_split_kernel, dim3((unsigned)n_streams), dim3(320), lds2, stream, mags, flux, energy,

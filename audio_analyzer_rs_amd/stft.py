@@ -233,28 +233,37 @@ def onset_flux(mags, prev_row=None, stream=None, offsets=None):
 
 
 ONSET_FLAG_FLUX, ONSET_FLAG_BURST, ONSET_FLAG_DETECTED, ONSET_FLAG_ENERGY_RISING, ONSET_FLAG_FIRED = 1, 2, 4, 8, 16
+ONSET_FLAG_TICK, ONSET_FLAG_GATED, ONSET_FLAG_CAL_CONSUMED = 32, 64, 128
+ONSET_MASK_TICK, ONSET_MASK_CAL_OPEN, ONSET_MASK_CAL_TIMEOUT = 1, 2, 4
+ONSET_UNCALIBRATED, ONSET_CALIBRATED, ONSET_CALIBRATING = 0, 1, 2
 
 
 def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offsets=None, suppress=None,
-                calibrated=True):
+                calibrated=True, initialized=None):
     """The onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
     531-535): burst floor, silence gate, energy EMA, FluxTracker, combined trigger, velocity,
     frames_since_onset gate.  All arguments are CUDA tensors: mags float32 [frames, bins]; flux,
-    energy, global_floor float32 [frames].  suppress (uint8 [frames], non-zero = inside the
-    metronome's tick guard, onset.rs:393-396; None = never) and calibrated (False = the latency
-    calibration is still running: nothing fires, onset.rs:404-440) are the transport's inputs.
-    state: None for a fresh detector, or the [bins + 3] tensor returned by a previous call.
-    offsets (CUDA int64 [n_streams + 1]): independent streams laid end to end, one wave each; state
-    is then [n_streams, bins + 3].
+    energy, global_floor float32 [frames].  The transport's inputs: suppress (uint8 [frames]: bit 0 = inside
+    the metronome's tick guard, onset.rs:393-396; bit 1 = calibration click played and the residual of an onset
+    at this frame plausible, :405-422; bit 2 = calibration timed out, :361-371; None = 0) and calibrated
+    (False / 0 = calibration running, click not played: nothing fires; True / 1 = done; 2 = calibrating:
+    completion is carried in the state, the first gated onset on a bit-1 frame completes it and is consumed,
+    flags bit 7, onset.rs:404-440).
+    state: None for a fresh detector, or the [bins + 4] tensor returned by a previous call.
+    offsets (CUDA int64 [n_streams + 1]): independent streams laid end to end; state is then
+    [n_streams, bins + 4] and initialized (CUDA int32 [n_streams], default: all ones when a state is
+    passed) says which streams carry one - a stream that has had no frame yet stays fresh.
     Returns (dict of per-frame tensors, state)."""
     import torch
 
     lib = _lib.load()
     nf, nb = mags.shape
-    initialized = state is not None
+    have_state = state is not None
     ns = _offsets_arg(offsets, nf) if offsets is not None else None
     if state is None:
-        state = torch.zeros(nb + 3 if ns is None else (ns, nb + 3), dtype=torch.float32, device=mags.device)
+        state = torch.zeros(nb + 4 if ns is None else (ns, nb + 4), dtype=torch.float32, device=mags.device)
+    elif tuple(state.shape) != ((nb + 4,) if ns is None else (ns, nb + 4)):
+        raise ValueError("state must hold bins + 4 floats per stream")
     out = {
         "flux": torch.empty(nf, dtype=torch.float32, device=mags.device),
         "energy_ema": torch.empty(nf, dtype=torch.float32, device=mags.device),
@@ -267,20 +276,30 @@ def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offse
     if suppress is not None and (suppress.dtype != torch.uint8 or suppress.numel() != nf or not suppress.is_cuda):
         raise ValueError("suppress must be a CUDA uint8 tensor with one entry per frame")
     sup = suppress.data_ptr() if suppress is not None else None
+    cal = int(calibrated)
+    if cal not in (0, 1, 2):
+        raise ValueError("calibrated must be 0 / False, 1 / True or 2")
     if nf and ns is not None:
-        init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
+        if initialized is None:
+            init = torch.full((ns,), 1 if have_state else 0, dtype=torch.int32, device=mags.device)
+        else:
+            init = initialized.to(device=mags.device, dtype=torch.int32).contiguous()
+            if init.numel() != ns:
+                raise ValueError("initialized must hold one int32 per stream")
         _lib.check(lib.aa_onset_gates_batch_device(
             mags.data_ptr(), offsets.data_ptr(), ns, nf, nb, flux.data_ptr(), energy.data_ptr(),
-            global_floor.data_ptr(), sup, 1 if calibrated else 0, state.data_ptr(), init.data_ptr(), out["flux"].data_ptr(),
+            global_floor.data_ptr(), sup, cal, state.data_ptr(), init.data_ptr(), out["flux"].data_ptr(),
             out["energy_ema"].data_ptr(), out["max_excess"].data_ptr(), out["burst_count"].data_ptr(),
             out["flags"].data_ptr(), out["velocity"].data_ptr(), st))
     elif nf:
         _lib.check(lib.aa_onset_gates_device(
             mags.data_ptr(), nf, nb, flux.data_ptr(), energy.data_ptr(), global_floor.data_ptr(), sup,
-            1 if calibrated else 0, state.data_ptr(), 1 if initialized else 0, out["flux"].data_ptr(),
+            cal, state.data_ptr(), 1 if have_state else 0, out["flux"].data_ptr(),
             out["energy_ema"].data_ptr(),
             out["max_excess"].data_ptr(), out["burst_count"].data_ptr(), out["flags"].data_ptr(),
             out["velocity"].data_ptr(), st))
+    elif not have_state:
+        state = None                                  # nothing seen: the detector is still fresh
     return out, state
 
 

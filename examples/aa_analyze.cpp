@@ -225,7 +225,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMalloc(&d_mag, sizeof(float) * (size_t)of * ob));
         for (float **p : {&d_flux, &d_energy, &d_gf, &d_oflux, &d_ema, &d_exc, &d_vel})
             CHECK_HIP(hipMalloc(p, sizeof(float) * (size_t)of));
-        CHECK_HIP(hipMalloc(&d_state, sizeof(float) * (size_t)(ob + 3)));
+        CHECK_HIP(hipMalloc(&d_state, sizeof(float) * (size_t)(ob + 4)));
         CHECK_HIP(hipMalloc(&d_cnt, sizeof(int32_t) * (size_t)of));
         CHECK_HIP(hipMalloc(&d_flags, (size_t)of));
         std::vector<float> gf = global_floor(of, 256, 64, ob);

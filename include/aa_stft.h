@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 3
+#define AA_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -209,19 +209,20 @@ int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t ch
 /* ---- onset front end: spectral flux + frame energy (src/analysis/onset.rs:261-291) ---- */
 /* First stage after the onset STFT: for every frame t of a magnitude
  * spectrogram mags_dev[n_frames][n_bins] (AA_OUT_MAG rows; the reference geometry is 256/64,
- * n_bins = 129)
+ * n_bins = 129; n_bins <= 4160)
  *   energy[t] = sum_i mag[t][i]
  *   flux[t]   = sum_i max(0, smooth3(mag[t])[i] - mag[t-1][i]) * (1 - i/n_bins)
  * with smooth3 the 3-bin mean (ends unsmoothed) and mag[-1] = prev_row_dev (NULL = zeros, the
- * detector's initial state, onset.rs:146; a shard passes its predecessor's last row).  The
- * reference accumulates in bin order in f32; here each frame is a wave reduction, so parity is
- * to 1e-5 relative, not bit-exact.  The detector logic after it (burst floors, FluxTracker,
- * gates: onset.rs:293-546) is sequential per stream and stays on the host. */
+ * detector's initial state, onset.rs:146; a shard passes its predecessor's last row).
+ * ABI version 4: one lane per frame walks the bins in order, i.e. both sums are the reference's own sequential
+ * f32 sums (no contraction, the weight and the division by 3 rounded as there): flux and energy are BIT-IDENTICAL to
+ * the sequential evaluation, for any split of the frames into calls or shards.  (Versions 1-3 reduced a frame
+ * across a wave: 1e-5.)  The rows of a block of 64 frames are fetched once, as one contiguous span. */
 int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins,
                          const float *prev_row_dev, float *flux_dev, float *energy_dev, void *stream);
 
 /* ---- onset detector: burst floor, gates and trackers (src/analysis/onset.rs:298-371, 531-535) ---- */
-/* The per-frame logic that follows the flux in the reference's onset thread ("next" row f-2):
+/* The per-frame logic that follows the flux in the reference's onset thread ("next" row f-2), on the device:
  *   per bin   r = mag / max(floor, max(global_floor, 0.01));  r > 2.5: burst, floor = 1.3 mag;
  *             else floor += (mag > floor ? 0.1 : 0.04) * (mag - floor)            (onset.rs:311-332)
  *   frame     burst_count, max_excess = max r; flux = 0 when burst_count < 2       (:337-339)
@@ -229,27 +230,50 @@ int aa_onset_flux_device(const float *mags_dev, int64_t n_frames, int32_t n_bins
  *             FluxTracker(1.5, 0.84, 0.89)::update -> flux_onset                   (:66-83, :158)
  *             bin_burst_onset = max_excess > 3 && burst_count >= 3; onset_detected (:355-357)
  *             energy_rising = energy > 1.5 ema (:373); velocity (:389-390)
- *             frames_since_onset gate (:402, :531-535)
- * and the two transport-dependent inputs of the decision (onset.rs:361-371, 385-440), supplied by the caller because
- * they come from the MusicalTransport, not from the spectrum (ABI version 3):
- *   suppress_dev  one byte per frame, non-zero = the metronome's nearest tick is closer than the tick guard
- *                 (tick_dist < TICK_GUARD_S * bpm / 60, :393-396): a detected onset there is dropped; NULL = never
- *   calibrated    0 = the latency calibration has not completed (:404-440, :361-371): onsets are detected but none
- *                 fires (the caller watches flags bit 2 for its click and flips the argument when it has its offset)
- * onset_fired = onset_detected && !suppressed && energy_rising && frames_since_onset >= 3 && calibrated.
+ *             gated = onset_detected && !suppressed_by_tick && energy_rising && frames_since_onset >= 3   (:402)
+ *             frames_since_onset = 0 when the reference sets onset_fired, or at a detected frame within 3 frames of
+ *             the last one; + 1 otherwise                                          (:535-539)
+ * What the decision takes from the MusicalTransport is supplied by the caller (it does not come from the spectrum):
+ *   frame_mask_dev  one byte per frame (NULL = 0, under AA_ONSET_CALIBRATING = AA_ONSET_MASK_CAL_OPEN):
+ *       AA_ONSET_MASK_TICK         the nearest metronome tick is inside the tick guard (tick_dist < TICK_GUARD_S * bpm
+ *                                  / 60, :393-396): a detected onset there is dropped (flags bit 5)
+ *       AA_ONSET_MASK_CAL_OPEN     the calibration click has been played and an onset stamped at this frame would leave
+ *                                  a plausible residual, 0 .. 0.5 s behind it (:405-422: target != 0, not rejected)
+ *       AA_ONSET_MASK_CAL_TIMEOUT  the calibration timeout has run out by this frame (:361-371)
+ *   calibrated
+ *       AA_ONSET_UNCALIBRATED  the calibration is running and its click has not been played: a gated onset is
+ *                              "pre-calibration noise" (:406-408) - nothing fires, frames_since_onset counts on
+ *       AA_ONSET_CALIBRATED    calibration_done: every gated onset is an event (flags bit 4)
+ *       AA_ONSET_CALIBRATING   calibration_done is CARRIED IN THE STATE (0 in a fresh detector): a frame with
+ *                              CAL_TIMEOUT sets it in front of its decision (:361-371); a gated onset on a frame with
+ *                              CAL_OPEN sets it and is CONSUMED by the calibration (flags bit 7, no event) - the
+ *                              reference sets onset_fired there without pushing the event (:424-428), so
+ *                              frames_since_onset restarts and the stream goes on calibrated; a gated onset on any other
+ *                              frame is ignored as under AA_ONSET_UNCALIBRATED (:406-408, :417-422).  The caller reads
+ *                              the residual off the frame index of the bit-7 frame (it owns the transport).
+ * (ABI version 3 had "non-zero = tick" and a 0 / 1 flag, under which a stream could not cross its own calibration
+ * click: the consuming onset must restart frames_since_onset, and whether it is gated depends on that counter.)
  * Inputs: magnitude rows [n_frames x n_bins], flux / frame energy per frame (aa_onset_flux_device),
  * global_floor per frame (= 10^(noise_floor_db/20) * n_bins / 2, onset.rs:299-300).
- * state_dev: n_bins + 3 floats {floors, energy_ema, tracker threshold, frames_since_onset (int
- * bits)}, updated in place; `initialized` = 0 starts a fresh detector.
+ * state_dev: n_bins + 4 floats {floors, energy_ema, tracker threshold, frames_since_onset (int bits),
+ * calibration_done (int bits)}, updated in place; `initialized` = 0 starts a fresh detector.  A call with
+ * n_frames == 0 leaves the state untouched (a fresh detector stays fresh: pass initialized = 0 again).
  * Outputs per frame: gated flux, energy EMA, max_excess, burst count, velocity and
- * flags = flux_onset | bin_burst_onset << 1 | onset_detected << 2 | energy_rising << 3 |
- * onset_fired << 4 | suppressed_by_tick << 5.  Every f32 operation is the reference's, in its order: all outputs are
- * bit-identical to the sequential evaluation on the same inputs.  Up to 192 bins (the onset geometry has 129) a stream
- * runs as one workgroup of five waves with the recurrences taken apart - the per-bin floors one lane per bin, the burst
- * count / largest excess of a frame as a column walk, the scalar chains in a wave of their own, a block of 32 frames
- * apart (a ten-minute stream: ~30 ms; one wave walking the frames took 313 ms); wider spectra keep the one-wave form. */
+ * flags = flux_onset | bin_burst_onset << 1 | onset_detected << 2 | energy_rising << 3 | event << 4 |
+ * suppressed_by_tick << 5 | gated << 6 | consumed_by_calibration << 7.  Every f32 operation is the reference's, in its
+ * order: all outputs are bit-identical to the sequential evaluation on the same inputs.  Up to 192 bins (the onset
+ * geometry has 129) a stream runs as one workgroup of five waves with the recurrences taken apart - the per-bin floors
+ * one lane per bin, the burst count / largest excess of a frame as a column walk, the scalar chains in a wave of their
+ * own, a block of 32 frames apart (a ten-minute stream: ~30 ms; one wave walking the frames took 313 ms) - at any
+ * number of streams (aa_onset_gates_batch_device); wider spectra keep the one-wave form. */
+enum { AA_ONSET_MASK_TICK = 1, AA_ONSET_MASK_CAL_OPEN = 2, AA_ONSET_MASK_CAL_TIMEOUT = 4 };
+enum { AA_ONSET_UNCALIBRATED = 0, AA_ONSET_CALIBRATED = 1, AA_ONSET_CALIBRATING = 2 };
+enum {
+    AA_ONSET_FLAG_FLUX = 1, AA_ONSET_FLAG_BURST = 2, AA_ONSET_FLAG_DETECTED = 4, AA_ONSET_FLAG_ENERGY_RISING = 8,
+    AA_ONSET_FLAG_EVENT = 16, AA_ONSET_FLAG_TICK = 32, AA_ONSET_FLAG_GATED = 64, AA_ONSET_FLAG_CAL_CONSUMED = 128
+};
 int aa_onset_gates_device(const float *mags_dev, int64_t n_frames, int32_t n_bins, const float *flux_dev,
-                          const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                          const float *energy_dev, const float *global_floor_dev, const uint8_t *frame_mask_dev,
                           int32_t calibrated, float *state_dev, int32_t initialized, float *out_flux_dev,
                           float *out_ema_dev, float *out_excess_dev, int32_t *out_count_dev, uint8_t *out_flags_dev,
                           float *out_velocity_dev, void *stream);
@@ -293,8 +317,9 @@ int aa_tuner_pitches_device(const float *mags_dev, const float *eff_floor_dev, i
  * streams (recordings, channels).  The batch forms take streams concatenated along the frame axis:
  * frame_offsets_dev[n_streams + 1] (device, ascending, [0] = 0, [n_streams] = n_frames_total);
  * stream s owns frames [off[s], off[s+1]) of every per-frame array.  State is [n_streams] x the
- * single-stream state; initialized_dev[n_streams] (NULL = all fresh).  One wave (gates) / one lane
- * per bin (floor) per stream; results are identical to per-stream calls.
+ * single-stream state; initialized_dev[n_streams] (NULL = all fresh).  One workgroup of five waves (gates up
+ * to 192 bins; one wave beyond) / one lane per bin (floor) per stream; results are identical to per-stream
+ * calls.  A stream without frames keeps its state as it was (and stays uninitialised if it was).
  * aa_onset_flux_batch_device: prev_rows_dev [n_streams][n_bins] or NULL (zeros) is the row before
  * each stream's first frame.  aa_tuner_pitches_device needs no batch form (frames independent). */
 int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
@@ -302,7 +327,7 @@ int aa_onset_flux_batch_device(const float *mags_dev, const int64_t *frame_offse
                                float *flux_dev, float *energy_dev, void *stream);
 int aa_onset_gates_batch_device(const float *mags_dev, const int64_t *frame_offsets_dev, int32_t n_streams,
                                 int64_t n_frames_total, int32_t n_bins, const float *flux_dev,
-                                const float *energy_dev, const float *global_floor_dev, const uint8_t *suppress_dev,
+                                const float *energy_dev, const float *global_floor_dev, const uint8_t *frame_mask_dev,
                                 int32_t calibrated, float *state_dev, const int32_t *initialized_dev,
                                 float *out_flux_dev, float *out_ema_dev, float *out_excess_dev,
                                 int32_t *out_count_dev, uint8_t *out_flags_dev, float *out_velocity_dev,
@@ -497,6 +522,19 @@ int aa_sharded_pipeline(aa_comm *comm_in, aa_comm *comm_out, const float *full_d
 int aa_stft_execute_sharded(aa_stft_plan *plan, aa_comm *comm_in, aa_comm *comm_out, const float *full_dev,
                             int64_t n_samples, int32_t root, float *local_dev, int64_t local_capacity,
                             float *rows_dev, float *out_dev, int32_t n_pieces, void *stream);
+
+/* ---- diagnostics (no reference counterpart; used by the test suite and bench.py) ---- */
+/* The flux kernel forms the reference's `/ 3.0` (onset.rs:268) in four instructions (x * RN(1/3), the exact remainder
+ * by one FMA, one correcting FMA, v_div_fixup_f32).  Runs the device function over the `count` consecutive f32 bit
+ * patterns from first_bits (count <= 2^32) and returns how many differ from the IEEE division (NaN == NaN):
+ * tests/test_gpu_parity.py sweeps all 2^32 and expects 0.  Synchronous. */
+int aa_diag_flux_div3_device(uint32_t first_bits, uint64_t count, uint64_t *mismatches_host);
+/* What the memory system delivers with NO arithmetic, in the product's access idiom (16-byte nontemporal loads and
+ * stores, persistent workgroups on contiguous runs): writes_per_read = 1 copies n_floats floats, = 2 stores every piece
+ * twice (dst_dev holds 2 * n_floats: the 1 : 2 read : write mix of the magnitude launch).  n_floats % 4 == 0, both
+ * buffers 16-byte aligned.  bench.py times it next to the headline kernel (roofline.copy_ceiling).  Asynchronous. */
+int aa_diag_stream_copy_device(const float *src_dev, float *dst_dev, int64_t n_floats, int32_t writes_per_read,
+                               void *stream);
 
 /* ---- streaming front end (ring-buffer ingest of stft.rs:198-201, 240-266) -- */
 typedef struct aa_stream aa_stream;

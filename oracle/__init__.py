@@ -15,6 +15,7 @@ from .capi import (  # noqa: F401
     Oracle,
     build_oracle,
     condition,
+    div3_mismatches,
     extract_pitches,
     interval,
     midi_from_freq,

@@ -60,6 +60,8 @@ class Oracle:
         lib.aao_stream_push.restype = ctypes.c_int64
         lib.aao_onset_flux.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p]
         lib.aao_onset_flux.restype = None
+        lib.aao_div3_mismatches.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+        lib.aao_div3_mismatches.restype = ctypes.c_uint64
         lib.aao_onset_gates.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, _f32p,
                                         ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _f32p,
                                         ctypes.POINTER(ctypes.c_int), _f32p, _f32p, _f32p,
@@ -242,16 +244,27 @@ def tuner_floor(mags, global_floor, state=None, initialized=False):
     return eff, st, bool(init.value)
 
 
+def div3_mismatches(first, count, cap=16):
+    """Bit patterns in [first, first + count) for which the flux kernel's three-operation x / 3 core differs from the
+    division (test support; releases the GIL, so ranges can run on threads).  Returns (count, first `cap` patterns)."""
+    out = (ctypes.c_uint32 * cap)()
+    n = Oracle.get().lib.aao_div3_mismatches(first, count, out, cap)
+    return int(n), [int(v) for v in out[:min(int(n), cap)]]
+
+
 def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False, suppress=None, calibrated=True):
     """Onset detector logic after the flux (src/analysis/onset.rs:298-371, 531-535), sequential f32; suppress
-    (uint8 per frame: inside the metronome's tick guard, :393-396) and calibrated (:404-440) are the transport's inputs.
-    Returns (dict of per-frame arrays, state [bins + 3], initialized)."""
+    (uint8 per frame: bit 0 inside the metronome's tick guard, :393-396; bit 1 calibration click played and the residual
+    plausible, :405-431; bit 2 calibration timed out, :361-371) and calibrated (False / 0: running, click not played;
+    True / 1: done; 2: calibrating, completion carried in the state) are the transport's inputs.
+    Returns (dict of per-frame arrays, state [bins + 4], initialized)."""
     mags = np.ascontiguousarray(mags, dtype=np.float32)
     nf, nb = mags.shape
     flux = np.ascontiguousarray(flux, dtype=np.float32)
     energy = np.ascontiguousarray(energy, dtype=np.float32)
     gf = np.ascontiguousarray(np.broadcast_to(np.asarray(global_floor, dtype=np.float32), (nf,)))
-    st = np.zeros(nb + 3, dtype=np.float32) if state is None else np.array(state, dtype=np.float32)
+    st = np.zeros(nb + 4, dtype=np.float32) if state is None else np.array(state, dtype=np.float32)
+    assert st.shape == (nb + 4,)
     init = ctypes.c_int(1 if initialized else 0)
     out = {"flux": np.empty(nf, np.float32), "energy_ema": np.empty(nf, np.float32),
            "max_excess": np.empty(nf, np.float32), "burst_count": np.empty(nf, np.int32),
@@ -259,7 +272,7 @@ def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False,
     Oracle.get().lib.aao_onset_gates(
         _ptr(mags), nf, nb, _ptr(flux), _ptr(energy), _ptr(gf),
         None if suppress is None else np.ascontiguousarray(suppress, dtype=np.uint8).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
-        1 if calibrated else 0, _ptr(st), ctypes.byref(init), _ptr(out["flux"]),
+        int(calibrated), _ptr(st), ctypes.byref(init), _ptr(out["flux"]),
         _ptr(out["energy_ema"]), _ptr(out["max_excess"]),
         out["burst_count"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
         out["flags"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _ptr(out["velocity"]))

@@ -437,19 +437,59 @@ void aao_onset_flux(const float *mags, int64_t n_frames, int n_bins, const float
     }
 }
 
+/* Test support, no reference counterpart: the product's flux kernel (csrc/aa_mel.hip, flux_div3) forms the
+ * reference's `/ 3.0` (onset.rs:268) as q0 = x * RN(1/3); e = fma(-3, q0, x); q = fma(e, RN(1/3), q0), followed by the
+ * hardware's division fix-up for the inputs the remainder step cannot serve (+-inf, whose remainder is NaN, and -0, whose
+ * sign the final add loses).  Counts the f32 bit patterns in [first, first + count) for which the three-operation
+ * core differs from the division (NaNs compare equal) and records the first `cap` of them: the whole 2^32 sweep must
+ * come back with exactly those three.                                                                          */
+__attribute__((target("fma"))) uint64_t aao_div3_mismatches(uint32_t first, uint64_t count, uint32_t *out, int cap)
+{
+    const float r = 0x1.555556p-2f;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        uint32_t bits = first + (uint32_t)i, ba, bb;
+        float x;
+        memcpy(&x, &bits, sizeof x);
+        const float q0 = x * r;
+        const float e = __builtin_fmaf(-3.0f, q0, x);
+        const float a = __builtin_fmaf(e, r, q0), b = x / 3.0f;
+        memcpy(&ba, &a, sizeof ba);
+        memcpy(&bb, &b, sizeof bb);
+        if (ba != bb && !(a != a && b != b)) {
+            if (out && bad < (uint64_t)cap)
+                out[bad] = bits;
+            ++bad;
+        }
+    }
+    return bad;
+}
+
 /* Rest of the onset detector's per-frame logic (src/analysis/onset.rs:298-371, 531-535) after
  * the flux: per-bin "rise-once, suppress" burst floor (:311-332), silence gate (:337-339),
  * energy EMA (:345-350), FluxTracker::update (:66-83, constructed :158 with (1.5, 0.84, 0.89)),
  * combined trigger (:355-357), energy_rising (:373), velocity (:389-390) and the
- * frames_since_onset gate (:402, 531-535).  The two transport-dependent inputs of the decision are arguments:
- * suppress[t] != 0 <=> the nearest metronome tick is inside the tick guard (:393-396; NULL = never) and
- * calibrated == 0 <=> the latency calibration is still running (:361-371, :404-440: nothing fires), i.e.
- * onset_fired = onset_detected && !suppressed && energy_rising && frames_since_onset >= 3 && calibrated.
- * state: n_bins floors, then energy_ema, tracker threshold, frames_since_onset (int bits).
+ * frames_since_onset gate (:402, 531-535).  What the decision takes from the MusicalTransport are arguments:
+ *   mask[t] (NULL = 0)  bit 0: the nearest metronome tick is inside the tick guard (:393-396: suppressed_by_tick);
+ *                       bit 1: the calibration click has been played and an onset stamped at this frame would leave a
+ *                              plausible residual, 0 .. 0.5 s behind it (:405-431: target != 0, not rejected);
+ *                       bit 2: the calibration timeout has run out by this frame (:361-371)
+ *   calibrated          0: calibration running, click not played yet - a gated onset is "pre-calibration noise", ignored
+ *                          (:406-408): nothing fires, frames_since_onset counts on;
+ *                       1: calibration_done;
+ *                       2: calibrating - calibration_done is CARRIED IN THE STATE (0 for a fresh detector): a frame with
+ *                          mask bit 2 sets it before its gates are evaluated (:361-371); a gated onset on a frame with
+ *                          mask bit 1 sets it and is CONSUMED by the calibration - the reference sets onset_fired = true
+ *                          without pushing an event (:424-428), so frames_since_onset restarts (:535-536) and the stream
+ *                          goes on calibrated; a gated onset on any other frame is ignored as under 0 (target not set, or
+ *                          the residual rejected :417-422).  mask == NULL under 2: every frame has bit 1, none bit 2.
+ * gated = onset_detected && !suppressed_by_tick && energy_rising && frames_since_onset >= 3   (:402)
+ * state: n_bins floors, then energy_ema, tracker threshold, frames_since_onset (int bits), calibration_done (int bits).
  * flags: bit0 flux_onset, bit1 bin_burst_onset, bit2 onset_detected, bit3 energy_rising,
- * bit4 onset_fired, bit5 suppressed_by_tick.  Plain f32 in the reference's operation order (-ffp-contract=off). */
+ * bit4 onset event pushed (gated && calibration_done), bit5 suppressed_by_tick, bit6 gated,
+ * bit7 gated and consumed by the calibration.  Plain f32 in the reference's operation order (-ffp-contract=off). */
 void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const float *flux,
-                     const float *energy, const float *global_floor, const uint8_t *suppress, int calibrated,
+                     const float *energy, const float *global_floor, const uint8_t *mask, int calibrated,
                      float *state, int *initialized,
                      float *out_flux, float *out_ema, float *out_excess, int32_t *out_count,
                      uint8_t *out_flags, float *out_velocity)
@@ -459,16 +499,21 @@ void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const floa
     const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
     float *fl = state;
     float ema, thr;
-    int32_t since;
+    int32_t since, cal_done = 0;
     if (*initialized) {
         ema = state[n_bins];
         thr = state[n_bins + 1];
         memcpy(&since, &state[n_bins + 2], sizeof since);
+        memcpy(&cal_done, &state[n_bins + 3], sizeof cal_done);
     } else {
         ema = 0.0f;
         thr = 0.0f;
         since = 4;
     }
+    if (calibrated != 2)
+        cal_done = calibrated == 1;
+    if (n_frames <= 0)
+        return;                                       /* nothing seen: the state stays as it was (and uninitialised) */
     for (int64_t t = 0; t < n_frames; ++t) {
         const float *m = mags + t * (int64_t)n_bins;
         float current_flux = flux[t];
@@ -508,15 +553,26 @@ void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const floa
         const int flux_onset = is_onset && current_flux > thr * multiplier;
         const int bin_burst_onset = max_bin_excess > 3.0f && bin_burst_count >= 3;
         const int onset_detected = flux_onset && bin_burst_onset;
+        const int mk = mask ? mask[t] : (calibrated == 2 ? 2 : 0);
+        /* onset.rs:361-371: the timeout completes the calibration in front of the frame's decision */
+        if (calibrated == 2 && (mk & 4))
+            cal_done = 1;
         const int energy_rising = frame_energy > ema * 1.5f;
-        /* onset.rs:393-396: suppressed_by_tick = tick_dist < tick_guard_beats (the transport's figure: an input here);
-         * :402-440: nothing fires before the latency calibration has completed (pre-calibration onsets are ignored or
-         * consumed by the calibration itself; its completion is the caller's to decide: `calibrated`) */
-        const int tick = onset_detected && suppress && suppress[t] != 0;
-        const int fired = onset_detected && !tick && energy_rising && since >= 3 && calibrated != 0;
+        /* onset.rs:393-396: suppressed_by_tick = tick_dist < tick_guard_beats (the transport's figure: an input here) */
+        const int tick = onset_detected && (mk & 1);
+        const int gated = onset_detected && !tick && energy_rising && since >= 3;       /* :402 */
+        int fired = 0, consumed = 0;
+        if (gated) {
+            if (cal_done) {
+                fired = 1;                            /* :433-446: the event is pushed */
+            } else if (calibrated == 2 && (mk & 2)) {
+                consumed = 1;                         /* :424-428: calibration_done = true; onset_fired = true */
+                cal_done = 1;
+            }                                         /* else :406-408 / :417-422: ignored */
+        }
         float vel = fmaxf(current_flux, max_bin_excess * 5.0f) / 50.0f;
         vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
-        if (fired || (onset_detected && since < 3))
+        if (fired || consumed || (onset_detected && since < 3))                        /* :535-539 */
             since = 0;
         else if (since < INT32_MAX)
             since += 1;
@@ -525,12 +581,13 @@ void aao_onset_gates(const float *mags, int64_t n_frames, int n_bins, const floa
         out_excess[t] = max_bin_excess;
         out_count[t] = bin_burst_count;
         out_flags[t] = (uint8_t)(flux_onset | (bin_burst_onset << 1) | (onset_detected << 2) |
-                                 (energy_rising << 3) | (fired << 4) | (tick << 5));
+                                 (energy_rising << 3) | (fired << 4) | (tick << 5) | (gated << 6) | (consumed << 7));
         out_velocity[t] = vel;
     }
     state[n_bins] = ema;
     state[n_bins + 1] = thr;
     memcpy(&state[n_bins + 2], &since, sizeof since);
+    memcpy(&state[n_bins + 3], &cal_done, sizeof cal_done);
 }
 
 /* -------------------------------------- tuner front: per-bin noise floor -- */

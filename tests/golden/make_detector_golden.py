@@ -41,6 +41,16 @@ def main():
     masked, _, _ = oracle.onset_gates(mags, flux, energy, gf, suppress=sup)
     uncal, _, _ = oracle.onset_gates(mags, flux, energy, gf, calibrated=False)
     out["gate_suppress"], out["gate_flags_masked"], out["gate_flags_uncalibrated"] = sup, masked["flags"], uncal["flags"]
+    # r5 (onset.rs:361-371, 404-440, 535-539): the stream across its own calibration - the click played 30 frames in
+    # front of the second onset, residuals plausible for 0.5 s = 375 frames; and a stream whose calibration times out
+    # at the third onset.  Mode 2: calibration_done travels in the state.
+    cal = np.zeros(len(flux), np.uint8)
+    cal[fired[1] - 30:fired[1] - 30 + 375] = 2
+    tmo = np.zeros(len(flux), np.uint8)
+    tmo[fired[2]:] = 4
+    for tag, mk in (("cal", cal), ("tmo", tmo)):
+        res, st, _ = oracle.onset_gates(mags, flux, energy, gf, suppress=mk, calibrated=2)
+        out["gate_mask_" + tag], out["gate_flags_" + tag], out["gate_state_" + tag] = mk, res["flags"], st
     # tuner geometry (stft.rs:169-174): 0.8 s of a chord
     y = _chord_signal(seconds=0.8, seed=78)
     tm = oracle.stft(y, 2048, 512, kind="mag")

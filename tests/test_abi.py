@@ -63,7 +63,9 @@ def test_header_is_plain_c_and_structs_match_the_ctypes_mirrors(tmp_path):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.aa_abi_version() == 3      # 3 (r4): aa_onset_gates[_batch]_device take the tick-guard mask and the calibration flag
+    # 4 (r5): the gates' per-frame mask has three bits and `calibrated` three modes, the state a fifth word
+    # (calibration_done); flags bits 6 / 7; the flux is bit-exact; aa_diag_*
+    assert lib.aa_abi_version() == 4
     assert isinstance(lib.aa_last_error(), bytes)
 
 

@@ -570,7 +570,8 @@ def test_downmix_matches_capture_rule(aa, torch_mod):
 
 def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
     """First "next" row: spectral flux + frame energy of the onset detector
-    (onset.rs:261-291) on the onset geometry, against the sequential f32 restatement."""
+    (onset.rs:261-291) on the onset geometry.  r5: one lane per frame walks the bins in order - the reference's own
+    sequential f32 sums - so both outputs are BIT-IDENTICAL to the restatement (rounds 1-4: a wave reduction, 1e-5)."""
     n, hop = 256, 64
     x = aa.signals.synth_corpus(31337, n + 4999 * hop)
     x[20_000:20_400] += 0.5 * aa.signals.lcg_noise(7, 0, 400).astype(np.float32)     # a burst
@@ -578,11 +579,87 @@ def test_onset_flux_and_energy(aa, oracle_mod, torch_mod):
     flux, energy = aa.onset_flux(mags)
     rf, re = oracle_mod.onset_flux(mags.cpu().numpy())
     assert flux.shape == (5000,)
-    assert np.max(np.abs(flux.cpu().numpy() - rf) / np.maximum(np.abs(rf), 1e-3)) < 1e-5
-    assert np.max(np.abs(energy.cpu().numpy() - re) / np.abs(re)) < 1e-5
+    assert np.array_equal(flux.cpu().numpy(), rf) and np.array_equal(energy.cpu().numpy(), re)
     # shards: second half with the last row of the first half carried in == whole
     f2, e2 = aa.onset_flux(mags[2500:].contiguous(), prev_row=mags[2499].contiguous())
     assert torch_mod.equal(f2, flux[2500:]) and torch_mod.equal(e2, energy[2500:])
+
+
+def test_onset_flux_sizes_and_streams(aa, oracle_mod, torch_mod):
+    """The flux kernel over what its staging can get wrong: bin counts on both sides of the flat span's limit (129) and
+    of the column tiles (113 bins each), frame counts around its 64-frame blocks, rows that start 4, 8 and 12 bytes
+    past a 16-byte boundary, a carried previous row, and streams laid end to end with starts in mid-block, several per
+    block, empty streams and more than 64 streams per block - every value bit for bit against the restatement."""
+    rng = np.random.default_rng(2025)
+    for nb in (2, 3, 5, 17, 65, 128, 129, 130, 226, 227, 257, 513):
+        for nf in (1, 2, 63, 64, 65, 128, 129, 300):
+            base = (rng.random((nf, nb)) ** 3).astype(np.float32)
+            base[rng.random(nf) < 0.2] *= 30.0
+            prev = (rng.random(nb) ** 3).astype(np.float32)
+            for shift in ((0, 1, 2, 3) if nb in (3, 129, 130) else (0,)):
+                buf = torch_mod.zeros(nf * nb + 4, device="cuda")
+                buf[shift:shift + nf * nb] = torch_mod.from_numpy(base).cuda().reshape(-1)
+                mags = buf[shift:shift + nf * nb].view(nf, nb)
+                for pv in (None, prev):
+                    f, e = aa.onset_flux(mags, prev_row=None if pv is None else torch_mod.from_numpy(pv).cuda())
+                    rf, re = oracle_mod.onset_flux(base, prev0=pv)
+                    assert np.array_equal(f.cpu().numpy(), rf), (nb, nf, shift, pv is None)
+                    assert np.array_equal(e.cpu().numpy(), re), (nb, nf, shift, pv is None)
+    for nb in (129, 257):
+        nf = 700
+        base = (rng.random((nf, nb)) ** 3).astype(np.float32)
+        mags = torch_mod.from_numpy(base).cuda()
+        layouts = [
+            [0, 1, 2, 3, 64, 65, 200, 200, 200, 333, 640, 700],                      # mid-block starts, empty streams
+            list(range(0, 140)) + [140 + 5 * i for i in range(1, 112)] + [700],        # > 64 starts in a block
+            [0, 700],
+            [0, 0, 0, 700],
+        ]
+        for lay in layouts:
+            offs = np.asarray(lay, np.int64)
+            ns = len(offs) - 1
+            prevs = (rng.random((ns, nb)) ** 3).astype(np.float32)
+            for pv in (None, prevs):
+                f, e = aa.onset_flux(mags, offsets=torch_mod.from_numpy(offs).cuda(),
+                                     prev_row=None if pv is None else torch_mod.from_numpy(pv).cuda())
+                f, e = f.cpu().numpy(), e.cpu().numpy()
+                for s_ in range(ns):
+                    lo, hi = int(offs[s_]), int(offs[s_ + 1])
+                    if hi > lo:
+                        rf, re = oracle_mod.onset_flux(base[lo:hi], prev0=None if pv is None else pv[s_])
+                        assert np.array_equal(f[lo:hi], rf) and np.array_equal(e[lo:hi], re), (nb, lay[:6], s_, pv is None)
+
+
+def test_flux_div3_exhaustive(aa):
+    """The flux kernel's four-instruction x / 3 (csrc/aa_mel.hip flux_div3) against the device's IEEE division over ALL
+    2^32 f32 bit patterns (NaN == NaN): not one may differ, or the flux is no longer the reference's sum."""
+    import ctypes
+
+    lib = aa.load_library()
+    bad = ctypes.c_uint64(123)
+    total = 0
+    for k in range(4):
+        aa._lib.check(lib.aa_diag_flux_div3_device(k << 30, 1 << 30, ctypes.byref(bad)))
+        total += bad.value
+    assert total == 0
+
+
+def test_diag_stream_copy(aa, torch_mod):
+    """aa_diag_stream_copy_device (bench.py's measured ceiling): a copy and the twice-stored form move the bytes they
+    claim to, for lengths around the workgroups' runs; bad arguments are refused."""
+    lib = aa.load_library()
+    for n in (4, 1024, 4096 + 4, 1 << 20, (1 << 20) + 12, 28_800_000):
+        src = torch_mod.randn(n, device="cuda")
+        dst = torch_mod.full((2 * n + 4,), float("nan"), device="cuda")
+        aa._lib.check(lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), n, 1, None))
+        torch_mod.cuda.synchronize()
+        assert torch_mod.equal(dst[:n], src) and bool(dst[n:].isnan().all())
+        aa._lib.check(lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), n, 2, None))
+        torch_mod.cuda.synchronize()
+        assert torch_mod.equal(dst[:n], src) and torch_mod.equal(dst[n:2 * n], src) and bool(dst[2 * n:].isnan().all())
+    assert lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), 6, 1, None) == aa._lib.AA_ERR_ARG
+    assert lib.aa_diag_stream_copy_device(src.data_ptr() + 4, dst.data_ptr(), 8, 1, None) == aa._lib.AA_ERR_ARG
+    assert lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), 8, 3, None) == aa._lib.AA_ERR_ARG
 
 
 @pytest.mark.parametrize("n,hop", [(256, 64), (1024, 256)])
@@ -635,14 +712,47 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
     got, _ = aa.onset_gates(mags, flux, energy, gfd, suppress=supd)
     assert not bool(((got["flags"] & aa.stft.ONSET_FLAG_FIRED).bool() & supd.bool()).any())
     assert int((got["flags"] & 32).bool().sum()) >= len(fired[::2])
+    # r5 (ABI version 4; onset.rs:361-371, 404-440, 535-539): the stream across its own calibration.  Mode 2 carries
+    # calibration_done in the state: the click "played" 40 frames in front of the third onset with residuals plausible
+    # for 375 frames, ticks on top of it, a timeout later on - one call and pieces cut around the consuming onset
+    cal = np.zeros(nf, np.uint8)
+    cal[fired[2] - 40:fired[2] - 40 + 375 * 64 // hop] = 2
+    both = cal.copy()
+    both[sup != 0] |= 1
+    tmo = np.zeros(nf, np.uint8)
+    tmo[fired[4]:] = 4
+    f_cpu, e_cpu = flux.cpu().numpy(), energy.cpu().numpy()
+    for mk in (None, cal, both, tmo):
+        mkd = None if mk is None else torch_mod.from_numpy(mk).cuda()
+        got, gstate = aa.onset_gates(mags, flux, energy, gfd, suppress=mkd, calibrated=2)
+        want, wstate, _ = oracle_mod.onset_gates(m_cpu, f_cpu, e_cpu, gf, suppress=mk, calibrated=2)
+        for key in want:
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+        assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32))
+        if mk is not tmo:
+            used = np.nonzero(want["flags"] & aa.stft.ONSET_FLAG_CAL_CONSUMED)[0]
+            assert len(used) == 1
+            for cut in (int(used[0]) - 3, int(used[0]) + 1, int(used[0]) + 33):
+                part = lambda t, lo, hi: None if t is None else t[lo:hi].contiguous()      # noqa: E731
+                o1, s1 = aa.onset_gates(mags[:cut].contiguous(), flux[:cut].contiguous(), energy[:cut].contiguous(),
+                                        gfd[:cut].contiguous(), suppress=part(mkd, 0, cut), calibrated=2)
+                o2, s2 = aa.onset_gates(mags[cut:].contiguous(), flux[cut:].contiguous(), energy[cut:].contiguous(),
+                                        gfd[cut:].contiguous(), suppress=part(mkd, cut, nf), calibrated=2, state=s1)
+                for key in got:
+                    assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), got[key]), (cut, key)
+                assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), cut
     # the one-wave form (spectra wider than 192 bins, or >= 256 streams) carries the same inputs: 513 bins
     mags1k = aa.Stft(1024, 256, output="mag")(xd)
     f1k, e1k = aa.onset_flux(mags1k)
     n1k = mags1k.shape[0]
     gf1k = np.full(n1k, 10.0 ** (-60.0 / 20.0) * 513 / 2.0, np.float32)
     sup1k = (np.arange(n1k) % 7 < 3).astype(np.uint8)
+    cal1k = ((np.arange(n1k) % 11 < 5) * 2 + sup1k).astype(np.uint8)
+    cal1k[n1k // 2:] |= 4
     for kw_gpu, kw_cpu in ((dict(suppress=torch_mod.from_numpy(sup1k).cuda()), dict(suppress=sup1k)),
-                           (dict(calibrated=False), dict(calibrated=False))):
+                           (dict(calibrated=False), dict(calibrated=False)),
+                           (dict(calibrated=2), dict(calibrated=2)),
+                           (dict(suppress=torch_mod.from_numpy(cal1k).cuda(), calibrated=2), dict(suppress=cal1k, calibrated=2))):
         got, gstate = aa.onset_gates(mags1k, f1k, e1k, torch_mod.from_numpy(gf1k).cuda(), **kw_gpu)
         want, wstate, _ = oracle_mod.onset_gates(mags1k.cpu().numpy(), f1k.cpu().numpy(), e1k.cpu().numpy(), gf1k, **kw_cpu)
         for key in want:
@@ -671,6 +781,13 @@ def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
             for key in want:
                 assert np.array_equal(got[key].cpu().numpy(), want[key]), (nb, nf, key)
             assert np.array_equal(gstate.cpu().numpy().view(np.uint32), wstate.view(np.uint32)), (nb, nf)
+            # calibrating (mode 2): plausible-residual windows and a timeout at random, the tick bits kept
+            mk = (sup | (2 * (rng.random(nf) < 0.3)) | (4 * (np.arange(nf) >= rng.integers(0, 2 * nf)))).astype(np.uint8)
+            got2, gstate2 = aa.onset_gates(mags, flux, energy, gfd, suppress=torch_mod.from_numpy(mk).cuda(), calibrated=2)
+            want2, wstate2, _ = oracle_mod.onset_gates(base, flux.cpu().numpy(), energy.cpu().numpy(), gf, suppress=mk, calibrated=2)
+            for key in want2:
+                assert np.array_equal(got2[key].cpu().numpy(), want2[key]), (nb, nf, key, "mode 2")
+            assert np.array_equal(gstate2.cpu().numpy().view(np.uint32), wstate2.view(np.uint32)), (nb, nf, "mode 2")
             if nf >= 33:
                 cut = int(rng.integers(1, nf))
                 o1, s1 = aa.onset_gates(mags[:cut].contiguous(), flux[:cut].contiguous(), energy[:cut].contiguous(),
@@ -723,7 +840,7 @@ def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
         flux, energy = aa.onset_flux(mags, offsets=offsets)
         gates, gstate = aa.onset_gates(mags, flux, energy, gf, offsets=offsets)
         eff, fstate = aa.tuner_floor(mags, gf, offsets=offsets)
-        assert gstate.shape == (len(lens), nb + 3) and fstate.shape == (len(lens), 3, nb)
+        assert gstate.shape == (len(lens), nb + 4) and fstate.shape == (len(lens), 3, nb)
         lo = 0
         for i, r in enumerate(rows):
             hi = lo + counts[i]
@@ -738,6 +855,61 @@ def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
             lo = hi
     with pytest.raises(aa.AaError):
         aa.onset_flux(mags, offsets=offsets[:-1].contiguous())
+
+
+def test_many_streams_and_empty_streams(aa, oracle_mod, torch_mod):
+    """r5: the five-wave gates at ANY stream count (rounds 1-4 fell back to one lone wave per stream from 256 streams
+    on): 700 streams of ragged lengths, some without a frame, in two calls - a stream that has had no frame yet stays
+    fresh (its state untouched, `initialized` 0) and starts in the second call; every stream bit for bit against the
+    restatement run stream by stream over both calls."""
+    rng = np.random.default_rng(99)
+    ns, nb = 700, 129
+    len1 = rng.integers(0, 90, ns)
+    len1[rng.random(ns) < 0.15] = 0
+    len2 = rng.integers(0, 70, ns)
+    len1[0], len2[0], len1[-1], len2[-1] = 0, 40, 0, 0
+    def make(lens):
+        nf = int(lens.sum())
+        base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
+        bursts = rng.random(nf) < 0.1
+        base[bursts] *= (4.0 + 20.0 * rng.random((int(bursts.sum()), nb))).astype(np.float32)
+        gf = (0.01 + 0.02 * rng.random(nf)).astype(np.float32)
+        mk = ((rng.random(nf) < 0.1) | (2 * (rng.random(nf) < 0.5))).astype(np.uint8)
+        return base, gf, mk, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b1, g1, m1, o1 = make(len1)
+    b2, g2, m2, o2 = make(len2)
+    dev = lambda a: torch_mod.from_numpy(a).cuda()          # noqa: E731
+    f1, e1 = aa.onset_flux(dev(b1), offsets=dev(o1))
+    r1, st1 = aa.onset_gates(dev(b1), f1, e1, dev(g1), offsets=dev(o1), suppress=dev(m1), calibrated=2)
+    init = dev((len1 > 0).astype(np.int32))
+    st_before = st1.clone()
+    f2, e2 = aa.onset_flux(dev(b2), offsets=dev(o2), prev_row=None)
+    r2, st2 = aa.onset_gates(dev(b2), f2, e2, dev(g2), offsets=dev(o2), suppress=dev(m2), calibrated=2, state=st1,
+                             initialized=init)
+    assert st2.data_ptr() == st1.data_ptr()
+    f1c, e1c, f2c, e2c = f1.cpu().numpy(), e1.cpu().numpy(), f2.cpu().numpy(), e2.cpu().numpy()
+    st2c, stbc = st2.cpu().numpy(), st_before.cpu().numpy()
+    for s_ in range(ns):
+        a0, a1, c0, c1 = int(o1[s_]), int(o1[s_ + 1]), int(o2[s_]), int(o2[s_ + 1])
+        state, initd = None, False
+        if a1 > a0:
+            rf, re = oracle_mod.onset_flux(b1[a0:a1])
+            assert np.array_equal(f1c[a0:a1], rf) and np.array_equal(e1c[a0:a1], re), s_
+            want, state, initd = oracle_mod.onset_gates(b1[a0:a1], rf, re, g1[a0:a1], suppress=m1[a0:a1], calibrated=2)
+            for key in want:
+                assert np.array_equal(r1[key][a0:a1].cpu().numpy(), want[key]), (s_, key)
+            assert np.array_equal(stbc[s_].view(np.uint32), state.view(np.uint32)), s_
+        else:
+            assert not stbc[s_].any(), s_                   # untouched (the mirror hands out zeros)
+        if c1 > c0:
+            rf, re = oracle_mod.onset_flux(b2[c0:c1])
+            assert np.array_equal(f2c[c0:c1], rf) and np.array_equal(e2c[c0:c1], re), s_
+            want, state, _ = oracle_mod.onset_gates(b2[c0:c1], rf, re, g2[c0:c1], suppress=m2[c0:c1], calibrated=2,
+                                                    state=state, initialized=initd)
+            for key in want:
+                assert np.array_equal(r2[key][c0:c1].cpu().numpy(), want[key]), (s_, key, "second call")
+        if state is not None:
+            assert np.array_equal(st2c[s_].view(np.uint32), state.view(np.uint32)), s_
 
 
 def test_cpp_example_host_program(aa, torch_mod, tmp_path):

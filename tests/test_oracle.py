@@ -176,9 +176,95 @@ def test_onset_gates_restatement(oracle_mod):
     for key in ("flux", "energy_ema", "max_excess", "burst_count", "velocity"):
         assert np.array_equal(m[key], out[key]), key
     assert np.array_equal(mf & 15, out["flags"] & 15)
-    # before the calibration has completed: everything detected, nothing fired
+    # before the calibration click has been played (onset.rs:406-408): everything detected, nothing fired, and a gated
+    # onset does NOT restart frames_since_onset - so the frames behind it may be gated too (bit 6 more often than bit 4)
     u, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, calibrated=False)
-    assert not np.any(u["flags"] & 16) and np.array_equal(u["flags"] & 15, out["flags"] & 15)
+    assert not np.any(u["flags"] & (16 | 128)) and np.array_equal(u["flags"] & 15, out["flags"] & 15)
+    assert np.array_equal(out["flags"] & 64, (out["flags"] & 16) << 2)         # calibrated: gated == event
+    assert np.all((u["flags"][fired] & 64) != 0) and int((u["flags"] & 64 > 0).sum()) >= len(fired)
+
+
+def test_onset_calibration_modes(oracle_mod):
+    """The stream that spans its own calibration (onset.rs:361-371, 404-440, 535-539): mode 2 carries
+    calibration_done in the state; the gated onset that completes the calibration is consumed (bit 7, no event) and
+    restarts frames_since_onset exactly as a fired one does."""
+    x = _burst_signal()
+    mags = oracle_mod.stft(x, 256, 64, kind="mag")
+    nf = mags.shape[0]
+    flux, energy = oracle_mod.onset_flux(mags)
+    gf = np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0)
+    cal, st_cal, _ = oracle_mod.onset_gates(mags, flux, energy, gf)
+    unc, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, calibrated=0)
+    fired = np.nonzero(cal["flags"] & 16)[0]
+    # (i) no mask: every frame is open - the first gated onset is consumed, the rest is the calibrated stream
+    m2, st2, _ = oracle_mod.onset_gates(mags, flux, energy, gf, calibrated=2)
+    want = cal["flags"].copy()
+    want[fired[0]] = (int(want[fired[0]]) & 0xEF) | 128
+    assert np.array_equal(m2["flags"], want)
+    assert st2[129 + 3].view(np.int32) == 1 and st_cal[129 + 3].view(np.int32) == 1
+    assert np.array_equal(st2[:129 + 3].view(np.uint32), st_cal[:129 + 3].view(np.uint32))
+    # (ii) the click is played at frame `t_open` and residuals are plausible for 0.5 s (375 frames) behind it: before
+    # that the stream is the uncalibrated one (gated onsets ignored, the counter runs on), the first gated onset
+    # inside the window is consumed, from there on onsets are events
+    t_open = int(fired[2]) - 40
+    mask = np.zeros(nf, np.uint8)
+    mask[t_open:t_open + 375] = 2
+    w, st_w, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=mask, calibrated=2)
+    used = np.nonzero(w["flags"] & 128)[0]
+    assert len(used) == 1 and t_open <= used[0] < t_open + 375
+    assert np.array_equal(w["flags"][:used[0]], unc["flags"][:used[0]])
+    assert not np.any(w["flags"][:used[0]] & 16) and np.any(w["flags"][used[0] + 1:] & 16)
+    assert np.all((w["flags"] & 64) >= ((w["flags"] & 16) << 2)) and (w["flags"][used[0]] & (64 | 16)) == 64
+    # ... and in two calls with the state carried, cut in front of and behind the consuming onset
+    for cut in (int(used[0]) - 5, int(used[0]) + 1, int(used[0]) + 400):
+        a, sa, ia = oracle_mod.onset_gates(mags[:cut], flux[:cut], energy[:cut], gf, suppress=mask[:cut], calibrated=2)
+        b, sb, _ = oracle_mod.onset_gates(mags[cut:], flux[cut:], energy[cut:], gf, suppress=mask[cut:], calibrated=2,
+                                          state=sa, initialized=ia)
+        for key in w:
+            assert np.array_equal(np.concatenate([a[key], b[key]]), w[key]), (cut, key)
+        assert np.array_equal(sb.view(np.uint32), st_w.view(np.uint32))
+    # (iii) a window in which no onset is gated (implausible residuals everywhere else): the calibration stays open
+    none = np.zeros(nf, np.uint8)
+    none[5:8] = 2
+    n, st_n, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=none, calibrated=2)
+    assert np.array_equal(n["flags"], unc["flags"]) and st_n[129 + 3].view(np.int32) == 0
+    # (iv) the timeout (onset.rs:361-371) completes it in front of the frame's own decision: the timed-out frame may fire
+    tmo = np.zeros(nf, np.uint8)
+    tmo[fired[3]:] = 4
+    t, st_t, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=tmo, calibrated=2)
+    assert np.array_equal(t["flags"][:fired[3]], unc["flags"][:fired[3]]) and not np.any(t["flags"] & 128)
+    ev = np.nonzero(t["flags"] & 16)[0]
+    assert len(ev) >= 1 and ev[0] >= fired[3] and st_t[129 + 3].view(np.int32) == 1
+    # (v) the tick guard keeps its meaning under every mode (bit 0), and a tick frame is never gated
+    both = mask.copy()
+    both[used[0] - 2:used[0] + 3] |= 1
+    k, _, _ = oracle_mod.onset_gates(mags, flux, energy, gf, suppress=both, calibrated=2)
+    assert (k["flags"][used[0]] & (32 | 64 | 128)) == 32
+    # (vi) no frames: the state comes back untouched and uninitialised
+    z, st_z, init_z = oracle_mod.onset_gates(mags[:0], flux[:0], energy[:0], gf)
+    assert not init_z and not st_z.any()
+
+
+def test_div3_core_is_the_division(oracle_mod):
+    """The flux kernel's x / 3 (csrc/aa_mel.hip flux_div3: multiply by RN(1/3), exact remainder by one FMA, one
+    correcting FMA) over ALL 2^32 f32 bit patterns against the division of onset.rs:268: exactly +inf, -inf (their
+    remainder is NaN) and -0 (the add loses its sign) differ - the three inputs the kernel hands to v_div_fixup_f32.
+    The device runs the same sweep through the whole function (tests/test_gpu_parity.py::test_flux_div3_exhaustive)."""
+    import threading
+
+    parts = 16
+    res = [None] * parts
+
+    def run(k):
+        res[k] = oracle_mod.div3_mismatches(k << 28, 1 << 28)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(parts)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    bad = sorted(b for n, bits in res for b in bits)
+    assert sum(n for n, _ in res) == 3 and bad == [0x7F800000, 0x80000000, 0xFF800000]
 
 
 def _chord_signal(seconds=3.0, sr=48000, seed=3):
@@ -422,7 +508,7 @@ def test_detector_restatements_vs_golden(oracle_mod):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detectors_golden.npz"))
     mags = oracle_mod.stft(g["onset_x"], 256, 64, kind="mag")
     flux, energy = oracle_mod.onset_flux(mags)
-    assert np.allclose(flux, g["onset_flux"], rtol=2e-6, atol=1e-6) and np.allclose(energy, g["onset_energy"], rtol=2e-6)
+    assert np.array_equal(flux, g["onset_flux"]) and np.array_equal(energy, g["onset_energy"])   # (sequential f32 sums)
     gates, state, _ = oracle_mod.onset_gates(mags, g["onset_flux"], g["onset_energy"],
                                             np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0))
     for k in ("burst_count", "flags"):
@@ -437,6 +523,15 @@ def test_detector_restatements_vs_golden(oracle_mod):
                                          calibrated=False)
     assert np.array_equal(masked["flags"], g["gate_flags_masked"]) and np.array_equal(uncal["flags"], g["gate_flags_uncalibrated"])
     assert int((g["gate_flags_masked"] & 32 > 0).sum()) >= 1 and not np.any(g["gate_flags_uncalibrated"] & 16)
+    # r5: a stream across its calibration click (mode 2: click played at a frame, plausible for 375 frames) and one that
+    # runs into the calibration timeout - flags and the carried calibration_done exactly
+    gf0 = np.float32(10.0 ** (-60.0 / 20.0) * 129 / 2.0)
+    for tag in ("cal", "tmo"):
+        got, st, _ = oracle_mod.onset_gates(mags, g["onset_flux"], g["onset_energy"], gf0, suppress=g["gate_mask_" + tag], calibrated=2)
+        assert np.array_equal(got["flags"], g["gate_flags_" + tag]), tag
+        assert np.array_equal(st.view(np.uint32), g["gate_state_" + tag].view(np.uint32)), tag
+    assert int((g["gate_flags_cal"] & 128 > 0).sum()) == 1 and int((g["gate_flags_cal"] & 16 > 0).sum()) >= 1
+    assert not np.any(g["gate_flags_tmo"] & 128) and int((g["gate_flags_tmo"] & 16 > 0).sum()) >= 1
     tm = oracle_mod.stft(g["tuner_x"], 2048, 512, kind="mag")
     nb = tm.shape[1]
     eff, tstate, _ = oracle_mod.tuner_floor(tm, np.float32(10.0 ** (-60.0 / 20.0) * nb / 2.0))

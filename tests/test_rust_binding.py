@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "aa_stft.h")
 SYS_RS = os.path.join(ROOT, "bindings", "rust", "aa_stft_sys.rs")
 FFT_RS = os.path.join(ROOT, "bindings", "rust", "fft.rs")
 
-C_TO_RUST = {"int": "c_int", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "size_t": "usize", "float": "f32",
+C_TO_RUST = {"int": "c_int", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "float": "f32",
              "double": "f64", "char": "c_char", "void": "c_void"}
 
 

@@ -45,11 +45,12 @@ print(f"  tuner_pitches {timed(lambda: aa.tuner_pitches(mags, eff, 48000 / 2048)
 mags256 = aa.Stft(256, 64, output="mag")(xd)
 nf, nb = mags256.shape
 gf = torch.full((nf,), float(10.0 ** (-60 / 20.0) * nb / 2.0), device="cuda")
-for ns in (1, 64, 1024, 4096):
+for ns in (1, 64, 256, 1024, 4096, 16384):
     offs = torch.tensor(np.linspace(0, nf, ns + 1).astype(np.int64), device="cuda")
     flux, energy = aa.onset_flux(mags256, offsets=offs)
+    df = timed(lambda: aa.onset_flux(mags256, offsets=offs), reps=5)
     dt = timed(lambda: aa.onset_gates(mags256, flux, energy, gf, offsets=offs), reps=2)
-    print(f"onset_gates, {nf} frames as {ns:5d} streams: {dt * 1e3:9.3f} ms")
+    print(f"{nf} frames as {ns:5d} streams: onset_flux {df * 1e3:9.3f} ms, onset_gates {dt * 1e3:9.3f} ms")
 for ns in (1, 16, 256):
     offs = torch.tensor(np.linspace(0, mags.shape[0], ns + 1).astype(np.int64), device="cuda")
     gft = torch.full((mags.shape[0],), 0.5, device="cuda")
