@@ -207,6 +207,7 @@ __device__ __forceinline__ void flux_walk(const float *cur, const float *prv, bo
             m_lo = m_i;
             m_i = m_hi;
         };
+        // (issuing the next batch's reads in front of the current batch's arithmetic was measured: +-0, twice the code)
         int i = i_lo;
         for (; i + kFluxCh <= i_hi; i += kFluxCh) {
             const float *cp = cur + (i + 1 - kb), *pp = pq + (i - kb);
@@ -268,26 +269,44 @@ __global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict_
     int *starts = reinterpret_cast<int *>(wsh + wsh_len);       // [64] stream that starts at the block's frame (+ 1)
     for (int q = lane; q < wsh_len; q += 64)
         wsh[q] = q + 1 < n_bins ? 1.0f - ((float)(q + 1) / (float)n_bins) : 0.0f;
+    // every wave owns a contiguous run of blocks (consecutive blocks share a row, and the stream cursor below moves on
+    // by one probe per block)
     const int64_t n_blocks = (n_frames + kFluxT - 1) / kFluxT;
+    const int64_t per = (n_blocks + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    if (b0 >= b1)
+        return;
     const uintptr_t mags_addr = reinterpret_cast<uintptr_t>(mags);
 
-    // ---- the flat span of a block: floats [s0, s1) of the spectrogram, fetched from the 16-byte boundary below s0.
-    // Pieces that lie inside the span are 16-byte loads; the (at most two) pieces that straddle an end of it are
-    // fetched float by float by lanes 0-3 (nothing outside the caller's rows is ever read) ----
+    // ---- the flat span of a block: floats [s0, s0 + n) of the spectrogram, fetched from the 16-byte boundary below s0.
+    // An interior block (a frame in front of it and more than a row behind it in the caller's buffer) is 33 unconditional
+    // 16-byte loads per lane; at the two ends of the spectrogram pieces that lie inside the span are 16-byte loads and
+    // the (at most two) pieces that straddle an end of it are fetched float by float by lanes 0-3: nothing outside the
+    // caller's rows is ever read ----
     v4f regs[FLAT ? kFluxV4 : 1];
     float edge_head = 0.0f, edge_tail = 0.0f;
-    auto span_of = [&](int64_t b, int64_t &s0, int64_t &n, int &lead) {
+    auto span_of = [&](int64_t b, int64_t &s0, int64_t &n, int &lead, bool &interior) {
         const int64_t t0 = b * kFluxT;
         s0 = (t0 > 0 ? t0 - 1 : 0) * n_bins;
         const int64_t te = t0 + kFluxT < n_frames ? t0 + kFluxT : n_frames;
         n = te * n_bins - s0;
         lead = (int)(((mags_addr + 4u * (uint64_t)s0) & 15u) >> 2);
+        // (33 pieces per lane reach 4 * 64 * 33 floats past the boundary: inside the buffer if that many rows follow)
+        interior = t0 > 0 && (n_frames - (t0 - 1)) * (int64_t)n_bins >= 4 * 64 * kFluxV4;
     };
     auto fetch_flat = [&](int64_t b) {
         int64_t s0, n;
         int lead;
-        span_of(b, s0, n, lead);
+        bool interior;
+        span_of(b, s0, n, lead, interior);
         const float *base = mags + s0 - lead;                    // 16-byte aligned
+        if (interior) {
+            const v4f *bp = reinterpret_cast<const v4f *>(base) + lane;
+#pragma unroll
+            for (int u = 0; u < kFluxV4; ++u)
+                regs[u] = bp[64 * u];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kFluxV4; ++u) {
             const int64_t j = 4 * (int64_t)(lane + 64 * u) - lead;   // first float of the piece, relative to s0
@@ -297,58 +316,79 @@ __global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict_
         edge_head = (lane < 4 && jh >= 0 && jh < n) ? mags[s0 + jh] : 0.0f;
         edge_tail = (lane < 4 && jt >= 0 && jt < n) ? mags[s0 + jt] : 0.0f;
     };
-    if (FLAT && (int64_t)blockIdx.x < n_blocks)
-        fetch_flat(blockIdx.x);
+    if (FLAT)
+        fetch_flat(b0);
 
-    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    // ---- the stream cursor (batches): plo = the last stream that starts at or in front of the block's first frame,
+    // probe = offsets[plo + lane] - the starts that can fall into the block.  Found once per wave by a 64-ary search
+    // across the lanes (under the first fetch), then moved on by ONE probe per block, itself fetched a block ahead ----
+    int plo = 0;
+    int64_t probe = INT64_MAX;
+    auto load_probe = [&](int lo) { return lo + lane < n_streams ? offsets[lo + lane] : INT64_MAX; };
+    if (offsets) {
+        const int64_t t0 = b0 * kFluxT;
+        int lo = 0, hi = n_streams;                              // the last stream with offsets[s] <= t0 is in [lo, hi)
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) >> 6;
+            const int idx = lo + lane * step;
+            const bool le = idx < hi && offsets[idx] <= t0;
+            const int c = __popcll(__ballot(le));                // monotone: a prefix of the lanes (lane 0 always)
+            const int nlo = lo + (c > 0 ? c - 1 : 0) * step;
+            hi = lo + c * step < hi ? lo + c * step : hi;
+            lo = nlo;
+        }
+        plo = lo;
+        probe = load_probe(plo);
+    }
+
+    for (int64_t b = b0; b < b1; ++b) {
         const int64_t t0 = b * kFluxT, t = t0 + lane;
         const bool live = t < n_frames;
         __syncthreads();                                         // (one wave: orders the LDS accesses of two blocks)
         int64_t s0, n;
         int lead;
-        span_of(b, s0, n, lead);
+        bool interior;
+        span_of(b, s0, n, lead, interior);
         if (FLAT) {
 #pragma unroll
             for (int u = 0; u < kFluxV4; ++u)
                 reinterpret_cast<v4f *>(tile)[lane + 64 * u] = regs[u];
-            __syncthreads();
-            const int pt = (int)((lead + n) >> 2);               // the piece that holds the span's last floats
-            if (lane < 4 && lane >= lead && lane - lead < n)
-                tile[lane] = edge_head;
-            if (lane < 4 && ((lead + n) & 3) != 0 && lane < (int)((lead + n) & 3) && 4 * pt + lane >= lead)
-                tile[4 * pt + lane] = edge_tail;
+            if (!interior) {
+                __syncthreads();
+                const int pt = (int)((lead + n) >> 2);           // the piece that holds the span's last floats
+                if (lane < 4 && lane >= lead && lane - lead < n)
+                    tile[lane] = edge_head;
+                if (lane < 4 && ((lead + n) & 3) != 0 && lane < (int)((lead + n) & 3) && 4 * pt + lane >= lead)
+                    tile[4 * pt + lane] = edge_tail;
+            }
         }
         starts[lane] = 0;
         __syncthreads();
-        if (FLAT && b + gridDim.x < n_blocks)
-            fetch_flat(b + gridDim.x);                           // in flight while this block is walked
+        if (FLAT && b + 1 < b1)
+            fetch_flat(b + 1);                                   // in flight while this block is walked
 
         // ---- which lanes start a stream, and which one ----
         bool first = false;
         const float *p0 = nullptr;
         if (offsets) {
-            int lo = 0, hi = n_streams;                          // the last stream with offsets[s] <= t0 is in [lo, hi)
-            while (hi - lo > 1) {
-                const int step = (hi - lo + 63) >> 6;
-                const int idx = lo + lane * step;
-                const bool le = idx < hi && offsets[idx] <= t0;
-                const int c = __popcll(__ballot(le));            // monotone: a prefix of the lanes (lane 0 always)
-                const int nlo = lo + (c - 1) * step;
-                hi = lo + c * step < hi ? lo + c * step : hi;
-                lo = nlo;
-            }
-            for (int s = lo; s < n_streams; s += 64) {           // the starts inside the block, 64 streams at a time
-                const int idx = s + lane;
-                const int64_t o = idx < n_streams ? offsets[idx] : INT64_MAX;
+            int lo = plo;
+            int64_t o = probe;
+            for (;;) {                                           // (one round, unless > 63 streams start inside the block)
                 if (o >= t0 && o < t0 + kFluxT)
-                    atomicMax(&starts[(int)(o - t0)], idx + 1);
-                if (__ballot(o >= t0 + kFluxT) != 0)
+                    atomicMax(&starts[(int)(o - t0)], lo + lane + 1);
+                const int c = __popcll(__ballot(o <= t0 + kFluxT));   // the next block's cursor: offsets ascend
+                if (c < 64) {
+                    plo = lo + (c > 0 ? c - 1 : 0);
                     break;
+                }
+                lo += 63;                                        // (lane 63's stream becomes lane 0's: it is the cursor so far)
+                o = load_probe(lo);
             }
+            probe = load_probe(plo);                             // (for the next block: in flight during the walk)
             __syncthreads();
             const int sf = starts[lane];
             first = sf != 0 || t == 0;
-            p0 = (first && prev0) ? prev0 + (int64_t)(sf - 1) * n_bins : nullptr;
+            p0 = (sf != 0 && prev0) ? prev0 + (int64_t)(sf - 1) * n_bins : nullptr;
         } else {
             first = t == 0;
             p0 = first ? prev0 : nullptr;
