@@ -1040,6 +1040,30 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     }
 }
 
+// r5: the kernel of rounds 1-4 walked the 13 harmonics of every peak one peak per lane - 780 of its 1310 vector
+// instructions per frame, executed for the ~10 lanes whose peak stands 5 x above its floor - and kept both rows, a byte per
+// bin and six per-peak arrays of n_bins entries in LDS (25.7 KB: six waves per CU, half of their time waiting).  Now:
+//   * the peak test runs on the rows as they arrive in registers (neighbours from the LDS copy of the magnitudes); all
+//     peaks go into a BIT MASK (one ballot per 64 bins), only the STRONG ones (magnitude >= 5 x floor: the others score 0 and
+//     can never pass the 50 % cutoff, stft.rs:489-491, 556-560) into the compacted list;
+//   * the harmonic search is FLATTENED over (peak, harmonic) pairs, 64 pairs per pass: the window of harmonic n
+//     (stft.rs:507-515: at most four bins) is four bits of the mask, its strongest peak found without a loop;
+//   * the sequential part of the walk - a found harmonic may not be found again (search_start >= last + 1, :511) - only
+//     matters where the windows of consecutive harmonics touch (fundamentals below ~70 Hz); every pair checks that
+//     against the previous window's end, and a peak with no such contact sums its 13 results in order (bit-identical to
+//     the loop); the others take the reference's loop, one peak per lane as before;
+//   * ghost suppression runs over (candidate, candidate) pairs across the lanes; the 2-bin dedupe keeps the accepted
+//     notes one per lane.
+// 17.7 KB of LDS per frame in flight at the tuner's 1025 bins (nine waves per CU).
+constexpr int kPitH = kMaxHarmonics - 1;            // harmonics n = 2 .. 14
+constexpr int kPitGroup = 64;                       // strong peaks per scoring pass
+__device__ __forceinline__ float pit_wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
 template <bool PREF>
 __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     const float *__restrict__ mags, const float *__restrict__ eff_floor, int64_t n_frames, int n_bins,
@@ -1049,18 +1073,20 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
 #pragma clang fp contract(off)
     extern __shared__ float pit_lds[];
     const int lane = threadIdx.x;
-    const int nbp = (n_bins + 3) & ~3;
-    float *m = pit_lds, *nf = m + nbp;
-    float *score = nf + nbp, *frac = score + max_peaks;        // per peak ordinal
-    // r3: the later stages reuse dead areas (every stage ends in a workgroup barrier) - 25.7 KB instead of 42 KB per
-    // block, six resident blocks per CU instead of three: the kept candidates land on the frame's rows (last read by
-    // the scoring), the sorted ones on score / frac (last read when the kept ones were picked)
-    float *kfrac = m, *kscore = nf;                            // kept (unsuppressed) candidates
-    float *sfrac = score, *sscore = frac;                      // sorted by score
-    int *peak_bin = reinterpret_cast<int *>(frac + max_peaks), *cand = peak_bin + max_peaks;
-    unsigned char *is_peak = reinterpret_cast<unsigned char *>(cand + max_peaks);
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int nbp = (n_bins + 3) & ~3, nw = (n_bins + 63) >> 6;
     const int half_size = n_bins;
+    float *m = pit_lds;
+    uint32_t *mask32 = reinterpret_cast<uint32_t *>(m + nbp);              // [2 nw + 2] peak bits, 64 bins per pair of words
+    int *peak_bin = reinterpret_cast<int *>(mask32 + 2 * nw + 2);           // strong peaks, bin order
+    float *peak_nf = reinterpret_cast<float *>(peak_bin + max_peaks);
+    float *frac = peak_nf + max_peaks, *score = frac + max_peaks;
+    uint32_t *hw = reinterpret_cast<uint32_t *>(score + max_peaks);         // [64][13] harmonic results of a group
+    float *hm = reinterpret_cast<float *>(hw + kPitGroup * kPitH);
+    // later stages on dead areas (every stage ends in a workgroup barrier)
+    int *cand = peak_bin;
+    float *kfrac = peak_nf, *kscore = max_peaks <= kPitGroup * kPitH ? reinterpret_cast<float *>(hw) : hm + kPitGroup * kPitH;
+    float *sfrac = frac, *sscore = score;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     constexpr int kIt = 17;
     float rm[kIt], rn[kIt];
     auto row_loads = [&](int64_t t) {
@@ -1073,53 +1099,119 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
             }
         }
     };
-    if (PREF && (int64_t)blockIdx.x < n_frames)
-        row_loads(blockIdx.x);
+    // the reference's loop for one peak (stft.rs:497-540), used where harmonic windows touch
+    auto walk_slow = [&](int k, float frac_bin, float fund_mag, int &longest_run, int &total_harms) {
+        float acc = fund_mag;
+        int last = k, current_run = 0;
+        longest_run = 0;
+        total_harms = 0;
+        for (int n = 2; n <= kMaxHarmonics; ++n) {
+            const float expected_f = frac_bin * (float)n;
+            if (expected_f >= (float)half_size)
+                break;
+            const float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
+            int search_start = lo > 0.0f ? (int)lo : 0;
+            if (search_start < last + 1)
+                search_start = last + 1;
+            int search_end = (int)hi;
+            if (search_end > half_size - 1)
+                search_end = half_size - 1;
+            int best_hbin = 0;
+            float best_mag = 0.0f;
+            for (int h = search_start; h <= search_end; ++h)
+                if (((mask32[h >> 5] >> (h & 31)) & 1u) && m[h] > best_mag) {
+                    best_mag = m[h];
+                    best_hbin = h;
+                }
+            if (best_hbin != 0) {
+                acc += best_mag;
+                last = best_hbin;
+                current_run += 1;
+                total_harms += 1;
+            } else {
+                if (current_run > longest_run)
+                    longest_run = current_run;
+                current_run = 0;
+            }
+        }
+        if (current_run > longest_run)
+            longest_run = current_run;
+        return acc;
+    };
+    if ((int64_t)blockIdx.x < n_frames) {
+        if (PREF)
+            row_loads(blockIdx.x);
+    }
     for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {
         __syncthreads();
         if (PREF) {
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {
                 const int k = lane + 64 * i;
-                if (k < n_bins) {
+                if (k < n_bins)
                     m[k] = rm[i];
-                    nf[k] = rn[i];
-                    is_peak[k] = 0;
-                }
             }
-            if (t + gridDim.x < n_frames)
-                row_loads(t + gridDim.x);
         } else {
-            for (int k = lane; k < n_bins; k += 64) {
+            for (int k = lane; k < n_bins; k += 64)
                 m[k] = mags[t * n_bins + k];
-                nf[k] = eff_floor[t * n_bins + k];
-                is_peak[k] = 0;
-            }
         }
+        if (lane < 2 * nw + 2)
+            mask32[lane] = 0u;
+        for (int q = 64 + lane; q < 2 * nw + 2; q += 64)
+            mask32[q] = 0u;
         __syncthreads();
-        // ---- peaks, compacted in bin order ----
-        int n_peaks = 0;
-        for (int base = min_bin + 1; base < max_bin; base += 64) {
-            const int k = base + lane;
-            const bool pk = k < max_bin && m[k] > nf[k] && m[k] >= m[k - 1] && m[k] >= m[k + 1];
+        // ---- peaks: all into the bit mask, the strong ones compacted in bin order ----
+        int n_strong = 0;
+        auto peak_row = [&](int i, float mk, float nfk) {
+            const int k = lane + 64 * i;
+            const bool in = k > min_bin && k < max_bin;
+            const int kc = in ? k : 1;
+            const bool pk = in && mk > nfk && mk >= m[kc - 1] && mk >= m[kc + 1];
             const unsigned long long mask = __ballot(pk);
-            if (pk) {
-                is_peak[k] = 1;
-                peak_bin[n_peaks + __popcll(mask & lt)] = k;
+            if (lane == 0) {
+                mask32[2 * i] = (uint32_t)mask;
+                mask32[2 * i + 1] = (uint32_t)(mask >> 32);
             }
-            n_peaks += __popcll(mask);
+            const bool strong = pk && !(mk < nfk * 5.0f);
+            const unsigned long long smask = __ballot(strong);
+            if (strong) {
+                const int pos = n_strong + __popcll(smask & lt);
+                peak_bin[pos] = k;
+                peak_nf[pos] = nfk;
+            }
+            n_strong += __popcll(smask);
+        };
+        if (PREF) {
+#pragma unroll
+            for (int i = 0; i < kIt; ++i)
+                if (64 * i + 63 > min_bin && 64 * i < max_bin)        // (wave uniform)
+                    peak_row(i, rm[i], rn[i]);
+            if (t + gridDim.x < n_frames)
+                row_loads(t + gridDim.x);                             // in flight while this frame is scored
+        } else {
+            for (int i = (min_bin + 1) >> 6; 64 * i < max_bin; ++i) {
+                const int k = lane + 64 * i;
+                const bool ok = k < n_bins;
+                peak_row(i, ok ? m[k] : 0.0f, ok ? eff_floor[t * n_bins + k] : 0.0f);
+            }
         }
         __syncthreads();
-        // ---- harmonic-sum score, one peak per lane ----
+        int n_out = 0;
+        float my_freq = 0.0f, my_score = 0.0f;             // lane i < 8 carries output slot i
         float mx = 0.0f;
-        for (int p = lane; p < n_peaks; p += 64) {
-            const int k = peak_bin[p];
-            const float fund_mag = m[k];
-            float sc = 0.0f, fb = 0.0f;
-            if (!(fund_mag < nf[k] * 5.0f)) {
-                float frac_bin = (float)k;
+        // ---- harmonic-sum score of the strong peaks, 64 at a time ----
+        for (int g0 = 0; g0 < n_strong; g0 += kPitGroup) {
+            const int gcount = n_strong - g0 < kPitGroup ? n_strong - g0 : kPitGroup;
+            const bool mine = lane < gcount;
+            int k = 2;
+            float fund_mag = 0.0f, nfk = 0.0f, frac_bin = 0.0f;
+            if (mine) {
+                k = peak_bin[g0 + lane];
+                nfk = peak_nf[g0 + lane];
+                fund_mag = m[k];
+                frac_bin = (float)k;
                 if (k >= 1 && k + 1 < half_size) {
-                    const float y_l = logf(m[k - 1]), y_c = logf(m[k]), y_r = logf(m[k + 1]);
+                    const float y_l = logf(m[k - 1]), y_c = logf(fund_mag), y_r = logf(m[k + 1]);
                     const float denom = y_l - 2.0f * y_c + y_r;
                     float delta = 0.0f;
                     if (!(fabsf(denom) < 1e-30f)) {
@@ -1128,100 +1220,166 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
                     }
                     frac_bin = (float)k + delta;
                 }
-                fb = frac_bin;
-                float acc = fund_mag;
-                int last = k, longest_run = 0, current_run = 0, total_harms = 0;
-                for (int n = 2; n <= kMaxHarmonics; ++n) {
-                    const float expected_f = frac_bin * (float)n;
-                    if (expected_f >= (float)half_size)
-                        break;
-                    const float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
-                    int search_start = lo > 0.0f ? (int)lo : 0;
-                    if (search_start < last + 1)
-                        search_start = last + 1;
-                    int search_end = (int)hi;
-                    if (search_end > half_size - 1)
-                        search_end = half_size - 1;
-                    int best_hbin = 0;
+                frac[g0 + lane] = frac_bin;
+            }
+            __syncthreads();
+            // (peak, harmonic) pairs across the lanes: pair e = 13 * peak + (n - 2)
+            const int n_items = gcount * kPitH;
+            for (int e0 = 0; e0 < n_items; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < n_items) {
+                    const int sl = (e * 1261) >> 14;                  // e / 13 for e < 832
+                    const int n = e - kPitH * sl + 2;
+                    const float fb = frac[g0 + sl];
+                    const float expected_f = fb * (float)n;
+                    uint32_t word = 0u;
                     float best_mag = 0.0f;
-                    for (int h = search_start; h <= search_end; ++h)
-                        if (is_peak[h] && m[h] > best_mag) {
-                            best_mag = m[h];
-                            best_hbin = h;
+                    if (!(expected_f >= (float)half_size)) {
+                        const float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
+                        int ss = lo > 0.0f ? (int)lo : 0;
+                        int se = (int)hi;
+                        if (se > half_size - 1)
+                            se = half_size - 1;
+                        // the end of what the walk can have taken before: the peak's own bin (n = 2), or the previous window
+                        int pe;
+                        if (n == 2) {
+                            pe = peak_bin[g0 + sl];
+                        } else {
+                            pe = (int)ceilf(fb * (float)(n - 1) + 1.0f);
+                            if (pe > half_size - 1)
+                                pe = half_size - 1;
                         }
-                    if (best_hbin != 0) {
-                        acc += best_mag;
-                        last = best_hbin;
+                        const bool noconf = pe + 1 <= ss;
+                        int len = se - ss + 1;                        // 3 or 4 bins (fewer at the top of the spectrum)
+                        len = len < 0 ? 0 : (len > 4 ? 4 : len);
+                        const uint32_t w0 = mask32[ss >> 5], w1 = mask32[(ss >> 5) + 1];
+                        const uint64_t w64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+                        const uint32_t bits = (uint32_t)(w64 >> (ss & 31)) & ((1u << len) - 1u);
+                        int best_hbin = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if ((bits >> u) & 1u) {
+                                const float mg = m[ss + u];
+                                if (mg > best_mag) {
+                                    best_mag = mg;
+                                    best_hbin = ss + u;
+                                }
+                            }
+                        }
+                        word = (uint32_t)best_hbin | ((uint32_t)noconf << 24) | (1u << 25);
+                    }
+                    hw[e] = word;
+                    hm[e] = best_mag;
+                }
+            }
+            __syncthreads();
+            if (mine) {
+                // the 13 results of this lane's peak, in order: found -> add, run + 1; in range and not found -> run ends;
+                // past the spectrum -> the loop is over (stft.rs:503-505)
+                float acc = fund_mag;
+                int longest_run = 0, current_run = 0, total_harms = 0;
+                bool all_noconf = true;
+#pragma unroll
+                for (int hn = 0; hn < kPitH; ++hn) {
+                    const uint32_t word = hw[kPitH * lane + hn];
+                    const float mg = hm[kPitH * lane + hn];
+                    const bool in_range = (word >> 25) & 1u, found = (word & 0xFFFFFFu) != 0u;
+                    all_noconf = all_noconf && (!in_range || ((word >> 24) & 1u));
+                    if (found) {
+                        acc += mg;
                         current_run += 1;
                         total_harms += 1;
-                    } else {
-                        if (current_run > longest_run)
-                            longest_run = current_run;
+                    } else if (in_range) {
+                        longest_run = current_run > longest_run ? current_run : longest_run;
                         current_run = 0;
                     }
                 }
-                if (current_run > longest_run)
-                    longest_run = current_run;
-                if (!(longest_run < 3 && fund_mag < 15.0f * nf[k])) {
+                longest_run = current_run > longest_run ? current_run : longest_run;
+                if (!all_noconf)
+                    acc = walk_slow(k, frac_bin, fund_mag, longest_run, total_harms);
+                float sc = 0.0f;
+                if (!(longest_run < 3 && fund_mag < 15.0f * nfk)) {
                     const float log_score = log2f(0.5f + acc);
                     const float struct_mult =
                         (1.0f + (float)longest_run + (float)total_harms / 2.0f) / (1.0f + (float)kMaxHarmonics);
                     sc = log_score * struct_mult;
                 }
+                score[g0 + lane] = sc;
+                mx = fmaxf(mx, sc);
             }
-            score[p] = sc;
-            frac[p] = fb;
-            mx = fmaxf(mx, sc);
+            __syncthreads();
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            mx = fmaxf(mx, __shfl_xor(mx, off));
-        __syncthreads();
-        int n_out = 0;
-        float my_freq = 0.0f, my_score = 0.0f;             // lane i < 8 carries output slot i
-        if (n_peaks > 0 && mx != 0.0f) {
+        mx = pit_wave_max(mx);
+        if (n_strong > 0 && mx != 0.0f) {
             const float cutoff = mx * 0.5f;
-            // ---- candidates (score >= cutoff), bin order ----
+            // ---- candidates (score >= cutoff), bin order; cand aliases peak_bin: entry q is written at or below q ----
             int n_cand = 0;
-            for (int base = 0; base < n_peaks; base += 64) {
+            for (int base = 0; base < n_strong; base += 64) {
                 const int p = base + lane;
-                const bool c = p < n_peaks && score[p] >= cutoff;
+                const bool c = p < n_strong && score[p] >= cutoff;
                 const unsigned long long mask = __ballot(c);
                 if (c)
                     cand[n_cand + __popcll(mask & lt)] = p;
                 n_cand += __popcll(mask);
             }
             __syncthreads();
-            // ---- harmonic ghosts: one candidate per lane against all others; keep the rest ----
+            // ---- harmonic ghosts (stft.rs:562-585): candidate i against every other one ----
             int n_kept = 0;
-            for (int base = 0; base < n_cand; base += 64) {
-                const int i = base + lane;
-                bool keep = false;
-                float fi = 0.0f, si = 0.0f;
-                if (i < n_cand) {
-                    fi = frac[cand[i]];
-                    si = score[cand[i]];
-                    const float freq_i = fi * bin_width;
-                    bool suppressed = false;
-                    for (int j = 0; j < n_cand && !suppressed; ++j) {
-                        if (j == i)
-                            continue;
-                        const float freq_j = frac[cand[j]] * bin_width, score_j = score[cand[j]];
-                        const float ratio = freq_i / freq_j;
-                        const float nearest = roundf(ratio);
-                        if (nearest >= 2.0f && nearest <= 5.0f && fabsf(ratio / nearest - 1.0f) < 0.03f &&
-                            si < score_j * 1.05f)
-                            suppressed = true;
+            auto ghost = [&](float freq_i, float si, int j) {
+                const float freq_j = frac[cand[j]] * bin_width, score_j = score[cand[j]];
+                const float ratio = freq_i / freq_j;
+                const float nearest = roundf(ratio);
+                return nearest >= 2.0f && nearest <= 5.0f && fabsf(ratio / nearest - 1.0f) < 0.03f && si < score_j * 1.05f;
+            };
+            if (n_cand <= 32) {
+                // (i, j) pairs across the lanes: P = the power of two >= n_cand lanes per candidate i
+                int lg = 0;
+                while ((1 << lg) < n_cand)
+                    ++lg;
+                const int P = 1 << lg, per_pass = 64 >> lg;
+                const int j = lane & (P - 1);
+                for (int i0 = 0; i0 < n_cand; i0 += per_pass) {
+                    const int i = i0 + (lane >> lg);
+                    const bool ok = i < n_cand && j < n_cand;
+                    float fi = 0.0f, si = 0.0f;
+                    bool sup = false;
+                    if (ok) {
+                        fi = frac[cand[i]];
+                        si = score[cand[i]];
+                        sup = j != i && ghost(fi * bin_width, si, j);
                     }
-                    keep = !suppressed;
+                    const unsigned long long supm = __ballot(sup);
+                    const unsigned long long grp = P == 64 ? supm : (supm >> (lane & ~(P - 1))) & ((1ull << P) - 1ull);
+                    const bool keep = ok && j == 0 && grp == 0ull;
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        const int pos = n_kept + __popcll(mask & lt);
+                        kfrac[pos] = fi;
+                        kscore[pos] = si;
+                    }
+                    n_kept += __popcll(mask);
                 }
-                const unsigned long long mask = __ballot(keep);
-                if (keep) {
-                    const int pos = n_kept + __popcll(mask & lt);
-                    kfrac[pos] = fi;
-                    kscore[pos] = si;
+            } else {
+                for (int base = 0; base < n_cand; base += 64) {
+                    const int i = base + lane;
+                    bool keep = false;
+                    float fi = 0.0f, si = 0.0f;
+                    if (i < n_cand) {
+                        fi = frac[cand[i]];
+                        si = score[cand[i]];
+                        bool suppressed = false;
+                        for (int j = 0; j < n_cand && !suppressed; ++j)
+                            suppressed = j != i && ghost(fi * bin_width, si, j);
+                        keep = !suppressed;
+                    }
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        const int pos = n_kept + __popcll(mask & lt);
+                        kfrac[pos] = fi;
+                        kscore[pos] = si;
+                    }
+                    n_kept += __popcll(mask);
                 }
-                n_kept += __popcll(mask);
             }
             __syncthreads();
             // ---- descending score, equal scores in bin order: rank = elements that come first ----
@@ -1234,21 +1392,15 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
                 sscore[rank] = si;
             }
             __syncthreads();
-            // ---- 2-bin dedupe in score order, first 8; every lane walks the (short) list ----
-            float acc_frac[kMaxNotes];
+            // ---- 2-bin dedupe in score order, first 8 (stft.rs:594-607): lane a < 8 holds accepted note a ----
+            float acc_frac = 0.0f;
             int n_acc = 0;
             for (int i = 0; i < n_kept && n_acc < kMaxNotes; ++i) {
                 const float fi = sfrac[i];
-                bool conflict = false;
-#pragma unroll
-                for (int j = 0; j < kMaxNotes; ++j)
-                    if (j < n_acc && fabsf(fi - acc_frac[j]) < 2.0f)
-                        conflict = true;
+                const bool conflict = __ballot(lane < n_acc && fabsf(fi - acc_frac) < 2.0f) != 0ull;
                 if (!conflict) {
-#pragma unroll
-                    for (int j = 0; j < kMaxNotes; ++j)
-                        if (j == n_acc)
-                            acc_frac[j] = fi;
+                    if (lane == n_acc)
+                        acc_frac = fi;
                     ++n_acc;
                     const float freq = fi * bin_width;
                     if (freq >= min_freq && freq <= max_freq) {
@@ -1553,9 +1705,15 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
     int max_bin = (int)floorf(max_freq / bin_width);
     if (max_bin > n_bins - 2)
         max_bin = n_bins - 2;
-    const int max_peaks = n_bins;                    // plateaus can make neighbouring bins peaks
-    const int nbp = (n_bins + 3) & ~3;
-    const size_t lds = sizeof(float) * (size_t)(2 * nbp + 4 * max_peaks) + (size_t)nbp;
+    // peaks lie strictly between min_bin and max_bin (plateaus can make neighbouring bins peaks)
+    int max_peaks = max_bin - min_bin - 1;
+    if (max_peaks < 1)
+        max_peaks = 1;
+    const int nbp = (n_bins + 3) & ~3, nw = (n_bins + 63) >> 6;
+    size_t words = (size_t)nbp + (size_t)(2 * nw + 2) + 4 * (size_t)max_peaks + 2 * (size_t)(kPitGroup * kPitH);
+    if (max_peaks > kPitGroup * kPitH)
+        words += (size_t)max_peaks;                  // the kept scores do not fit the dead harmonic area
+    const size_t lds = sizeof(float) * words;
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
     int64_t blocks = n_frames < 16384 ? n_frames : 16384;

@@ -71,6 +71,8 @@ class Oracle:
                                             ctypes.c_float, ctypes.c_float, _f32p, _f32p,
                                             ctypes.POINTER(ctypes.c_int32)]
         lib.aao_extract_pitches.restype = None
+        lib.aao_extract_pitches_margin.argtypes = lib.aao_extract_pitches.argtypes + [_f32p]
+        lib.aao_extract_pitches_margin.restype = None
         lib.aao_pitch_tracker.argtypes = [_f32p, _f32p, ctypes.POINTER(ctypes.c_int32),
                                           ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64, _f32p,
                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, _f32p, _f32p,
@@ -279,9 +281,11 @@ def onset_gates(mags, flux, energy, global_floor, state=None, initialized=False,
     return out, st, bool(init.value)
 
 
-def extract_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0):
+def extract_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0, margin=False):
     """Multi-pitch extraction of the tuner (src/audio_io/stft.rs:443-620) per frame, sequential f32.
-    Returns (freq [frames, 8], score [frames, 8], count [frames])."""
+    Returns (freq [frames, 8], score [frames, 8], count [frames]); with margin=True also, per frame, the smallest
+    relative distance of any value the frame's decisions hang on to the boundary of its comparison (test support: a
+    frame with a margin of ~1e-7 can come out differently under a logf that differs in its last bit)."""
     mags = np.ascontiguousarray(mags, dtype=np.float32)
     eff_floor = np.ascontiguousarray(eff_floor, dtype=np.float32)
     nf, nb = mags.shape
@@ -289,6 +293,12 @@ def extract_pitches(mags, eff_floor, bin_width, min_freq=24.0, max_freq=10000.0)
     freq = np.zeros((nf, 8), np.float32)
     score = np.zeros((nf, 8), np.float32)
     count = np.zeros(nf, np.int32)
+    if margin:
+        mg = np.zeros(nf, np.float32)
+        Oracle.get().lib.aao_extract_pitches_margin(_ptr(mags), _ptr(eff_floor), nf, nb, bin_width, min_freq, max_freq,
+                                                    _ptr(freq), _ptr(score),
+                                                    count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(mg))
+        return freq, score, count, mg
     Oracle.get().lib.aao_extract_pitches(_ptr(mags), _ptr(eff_floor), nf, nb, bin_width, min_freq, max_freq,
                                          _ptr(freq), _ptr(score),
                                          count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))

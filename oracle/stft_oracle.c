@@ -647,9 +647,22 @@ void aao_tuner_floor(const float *mags, int64_t n_frames, int n_bins, const floa
  * out_freq / out_score: [n_frames][8], unused slots 0; out_count: notes per frame. */
 #define AAO_MAX_NOTES 8
 #define AAO_MAX_HARMONICS 14
-void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
-                         float bin_width, float min_freq, float max_freq, float *out_freq,
-                         float *out_score, int32_t *out_count)
+/* rel. distance of a to the boundary b of a comparison the frame's result hangs on */
+static inline void tie_margin(float *margin, float a, float b)
+{
+    const float d = fabsf(a - b) / fmaxf(fabsf(b), 1e-30f);
+    if (d < *margin)
+        *margin = d;
+}
+/* out_margin (nullable; test support): per frame the smallest relative distance of any float the frame's decisions
+ * hang on to the boundary of its comparison - harmonic windows (expected_f against the integers and the spectrum's
+ * end), the 50 % cutoff, the ghost test, the score order, the 2-bin dedupe, the frequency range.  Comparisons of INPUT
+ * values alone (peak tests, 5 x / 15 x floor) are not counted: they cannot differ between two evaluations.  A frame in
+ * which a 1-ulp difference of logf / log2f can change the result has a margin of ~1e-7; any other frame must come out
+ * of every correct evaluation with the same notes. */
+static void extract_pitches_impl(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                                 float bin_width, float min_freq, float max_freq, float *out_freq,
+                                 float *out_score, int32_t *out_count, float *out_margin)
 {
     const int half_size = n_bins;
     int min_bin = (int)ceilf(min_freq / bin_width);
@@ -670,6 +683,9 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
         for (int i = 0; i < AAO_MAX_NOTES; ++i)
             of[i] = os[i] = 0.0f;
         out_count[t] = 0;
+        float margin = INFINITY;
+        if (out_margin)
+            out_margin[t] = margin;
         if (min_bin >= max_bin)
             continue;
         memset(is_peak, 0, (size_t)half_size);
@@ -696,6 +712,8 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
                 if (!(fabsf(denom) < 1e-30f)) {
                     delta = 0.5f * (y_l - y_r) / denom;
                     delta = delta < -1.0f ? -1.0f : (delta > 1.0f ? 1.0f : delta);
+                } else {
+                    margin = 0.0f;                      /* (a vanishing curvature: the branch itself is the tie) */
                 }
                 frac_bin = (float)k + delta;
             }
@@ -704,8 +722,10 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
             int last = k, longest_run = 0, current_run = 0, total_harms = 0;
             for (int n = 2; n <= AAO_MAX_HARMONICS; ++n) {
                 const float expected_f = frac_bin * (float)n;
+                tie_margin(&margin, expected_f, (float)half_size);
                 if (expected_f >= (float)half_size)
                     break;
+                tie_margin(&margin, expected_f, roundf(expected_f));
                 float lo = floorf(expected_f - 1.0f), hi = ceilf(expected_f + 1.0f);
                 int search_start = lo > 0.0f ? (int)lo : 0;
                 if (search_start < last + 1)
@@ -749,9 +769,12 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
             continue;
         const float cutoff = max_score * 0.5f;
         int n_cand = 0;
-        for (int p = 0; p < n_peaks; ++p)
+        for (int p = 0; p < n_peaks; ++p) {
+            if (scores[peak_bins[p]] != 0.0f)
+                tie_margin(&margin, scores[peak_bins[p]], cutoff);
             if (scores[peak_bins[p]] >= cutoff)
                 cand[n_cand++] = peak_bins[p];
+        }
         /* harmonic ghosts: freq_i ~ N freq_j (N = 2..5) with a score below 1.05 x that of j */
         int n_kept = 0;
         for (int i = 0; i < n_cand; ++i) {
@@ -763,6 +786,13 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
                 const float freq_j = frac_bins[cand[j]] * bin_width, score_j = scores[cand[j]];
                 const float ratio = freq_i / freq_j;
                 const float nearest = roundf(ratio);
+                if (out_margin && ratio > 1.4f && ratio < 5.6f) {
+                    tie_margin(&margin, ratio, floorf(ratio) + 0.5f);
+                    if (nearest >= 2.0f && nearest <= 5.0f) {
+                        tie_margin(&margin, fabsf(ratio / nearest - 1.0f), 0.03f);
+                        tie_margin(&margin, score_i, score_j * 1.05f);
+                    }
+                }
                 if (nearest >= 2.0f && nearest <= 5.0f && fabsf(ratio / nearest - 1.0f) < 0.03f &&
                     score_i < score_j * 1.05f)
                     suppressed = 1;
@@ -770,6 +800,10 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
             if (!suppressed)
                 kept[n_kept++] = cand[i];
         }
+        for (int i = 0; out_margin && i < n_kept; ++i)
+            for (int j = i + 1; j < n_kept; ++j)
+                if (scores[kept[i]] != scores[kept[j]])
+                    tie_margin(&margin, scores[kept[i]], scores[kept[j]]);
         /* descending score, stable (insertion sort) */
         for (int i = 1; i < n_kept; ++i) {
             const int b = kept[i];
@@ -784,9 +818,11 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
         for (int i = 0; i < n_kept && n_dedup < AAO_MAX_NOTES; ++i) {
             const float frac_i = frac_bins[kept[i]];
             int conflict = 0;
-            for (int j = 0; j < n_acc; ++j)
+            for (int j = 0; j < n_acc; ++j) {
+                tie_margin(&margin, fabsf(frac_i - frac_bins[acc[j]]), 2.0f);
                 if (fabsf(frac_i - frac_bins[acc[j]]) < 2.0f)
                     conflict = 1;
+            }
             if (!conflict) {
                 acc[n_acc++] = kept[i];
                 ++n_dedup;
@@ -795,6 +831,8 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
         int n_out = 0;
         for (int i = 0; i < n_acc; ++i) {
             const float freq = frac_bins[acc[i]] * bin_width;
+            tie_margin(&margin, freq, min_freq);
+            tie_margin(&margin, freq, max_freq);
             if (freq >= min_freq && freq <= max_freq) {
                 of[n_out] = freq;
                 os[n_out] = scores[acc[i]];
@@ -802,6 +840,8 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
             }
         }
         out_count[t] = n_out;
+        if (out_margin)
+            out_margin[t] = margin;
     }
     free(is_peak);
     free(peak_bins);
@@ -809,6 +849,20 @@ void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_fr
     free(frac_bins);
     free(cand);
     free(kept);
+}
+void aao_extract_pitches(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                         float bin_width, float min_freq, float max_freq, float *out_freq,
+                         float *out_score, int32_t *out_count)
+{
+    extract_pitches_impl(mags, eff_floor, n_frames, n_bins, bin_width, min_freq, max_freq, out_freq, out_score,
+                         out_count, NULL);
+}
+void aao_extract_pitches_margin(const float *mags, const float *eff_floor, int64_t n_frames, int n_bins,
+                                float bin_width, float min_freq, float max_freq, float *out_freq,
+                                float *out_score, int32_t *out_count, float *out_margin)
+{
+    extract_pitches_impl(mags, eff_floor, n_frames, n_bins, bin_width, min_freq, max_freq, out_freq, out_score,
+                         out_count, out_margin);
 }
 
 /* PitchTracker::process (src/audio_io/stft.rs:28-117) over a sequence of frames: hit / miss

@@ -974,26 +974,34 @@ def test_cpp_example_host_program(aa, torch_mod, tmp_path):
 
 def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
     """Rest of "next" row f-1 up to the PitchTracker: multi-pitch extraction (stft.rs:443-620) on
-    the tuner geometry, fed with the GPU magnitudes and effective floor.  Note counts, order and
-    the integer decisions agree with the sequential restatement; frequencies and scores to 1e-5
-    relative (the device's logf / log2f are not libm's bits: a decision may flip on an exact tie,
-    so a frame in a thousand may differ)."""
+    the tuner geometry, fed with the GPU magnitudes and effective floor.  Every frame's notes - count, order,
+    frequencies and scores to 1e-5 - equal the sequential restatement's, EXCEPT in frames that the restatement itself
+    marks as ties: the device's logf / log2f are not libm's bits, and where a value a decision hangs on (a harmonic
+    window's edge frac * n against an integer, a score against the cutoff, ...) sits within 1e-5 relative of its
+    boundary, the last bit of a logarithm can turn it (r5: one frame in 5622 of the corpus - frac * 13 = 60.999996 -
+    found its thirteenth harmonic in another window).  Such frames must be <= 0.1 % and all of them marked."""
     from test_oracle import _chord_signal
 
     sr, n, hop = 48000, 2048, 512
-    x = np.concatenate([_chord_signal(seed=21), aa.signals.synth_corpus(5, 3 * sr)[: 3 * sr]]).astype(np.float32)
+    x = np.concatenate([_chord_signal(seed=21), aa.signals.synth_corpus(5, 63 * sr)[: 63 * sr]]).astype(np.float32)
     mags = aa.Stft(n, hop, output="mag")(torch_mod.from_numpy(x).cuda())
     nf, nb = mags.shape
     gf = torch_mod.full((nf,), float(10.0 ** (-60.0 / 20.0) * nb / 2.0), device="cuda")
     eff, _ = aa.tuner_floor(mags, gf)
     freq, score, count = aa.tuner_pitches(mags, eff, sr / n)
-    rf, rs, rc = oracle_mod.extract_pitches(mags.cpu().numpy(), eff.cpu().numpy(), sr / n)
+    rf, rs, rc, margin = oracle_mod.extract_pitches(mags.cpu().numpy(), eff.cpu().numpy(), sr / n, margin=True)
     freq, score, count = freq.cpu().numpy(), score.cpu().numpy(), count.cpu().numpy()
-    same = count == rc
-    assert same.mean() > 0.999 and int(rc.max()) >= 3 and (rc > 0).mean() > 0.5
-    assert np.allclose(freq[same], rf[same], rtol=1e-5, atol=0.0)
-    assert np.allclose(score[same], rs[same], rtol=1e-5, atol=1e-6)
+    assert int(rc.max()) >= 3 and (rc > 0).mean() > 0.5
+    differs = (count != rc) | ~np.all(np.isclose(freq, rf, rtol=1e-5, atol=0.0), axis=1) | \
+        ~np.all(np.isclose(score, rs, rtol=1e-5, atol=1e-6), axis=1)
+    assert differs.mean() <= 1e-3, int(differs.sum())
+    assert np.all(margin[differs] < 1e-5), (np.nonzero(differs)[0][:8], margin[differs][:8])
     assert np.all(freq[np.arange(8)[None, :] >= count[:, None]] == 0.0)
+    # the marks themselves: a minority of the frames (a frame holds ~100 harmonic windows, each with an integer edge
+    # somewhere: 22 % of the frames have one within 1e-5 relative, 3 % within 1e-6; the frames that actually differ
+    # sit at ~1e-7, the resolution of the f32 values themselves)
+    assert (margin < 1e-5).mean() < 0.5, float((margin < 1e-5).mean())
+    assert np.all(margin[differs] < 1e-6), margin[differs][:8]
     # degenerate spectra: plateaus make every bin a peak (more peaks than bins / 2), zeros, huge values
     flat = torch_mod.full((3, nb), 2.0, device="cuda")
     flat[1] = 0.0
