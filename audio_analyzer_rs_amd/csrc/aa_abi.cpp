@@ -1265,6 +1265,18 @@ int aa_stft_execute_sharded(aa_stft_plan *p, aa_comm *cin, aa_comm *cout, const 
 {
     if (!p || !cin || !cout)
         return fail(AA_ERR_ARG, "aa_stft_execute_sharded: NULL plan or communicator");
+    if (aa_comm_device_index(cin) != p->device || aa_comm_device_index(cout) != p->device)
+        return fail(AA_ERR_ARG, "aa_stft_execute_sharded: the plan lives on device %d, the communicators on %d / %d",
+                    p->device, aa_comm_device_index(cin), aa_comm_device_index(cout));
+    // the wave kernels stage 16-byte pieces of SAMPLES: from an odd sample buffer every piece would run on the generic
+    // kernel of the same length instead - rows equal to rounding, but no longer bit-equal to the whole launch, which
+    // callers of the sharded form rely on (the shards' rows ARE the whole's rows).  Refused rather than silently
+    // different.  (Magnitude / complex rows may start anywhere: a shard's slice of a [frames][513] slab does; the fused
+    // mel rows are stored as 16-byte pieces.)
+    const bool mel_rows = p->cfg.output == AA_OUT_LOGMEL || p->cfg.output == AA_OUT_MFCC;
+    if ((reinterpret_cast<uintptr_t>(local_dev) & 15u) || (mel_rows && (reinterpret_cast<uintptr_t>(rows_dev) & 15u)))
+        return fail(AA_ERR_ARG, "aa_stft_execute_sharded: local_dev (and rows_dev of a mel plan) must be 16-byte aligned (%p, %p)",
+                    (void *)local_dev, (void *)rows_dev);
     const int64_t total = aa_stft_num_frames(p, n_samples);
     int64_t f0 = 0, f1 = 0, s0 = 0, s1 = 0;
     int rc = aa_shard_frames(total, aa_comm_world(cin), aa_comm_rank(cin), &f0, &f1);

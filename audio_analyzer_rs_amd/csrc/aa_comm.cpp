@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #define fail(...) aa::abi_fail(__VA_ARGS__)
@@ -196,6 +197,8 @@ struct aa_comm {
     std::vector<hipEvent_t> events;
 };
 
+int aa_comm_device_index(const aa_comm *c) { return c ? c->device : -1; }
+
 extern "C" {
 
 const char *aa_comm_backend(void)
@@ -307,16 +310,16 @@ int aa_scatter_samples_piece(aa_comm *c, const float *full_dev, int64_t n_sample
 {
     if (!c || n_samples < 0 || n_fft <= 0 || hop <= 0 || root < 0 || root >= c->world || local_capacity < 0 ||
         n_pieces <= 0 || piece < 0 || piece >= n_pieces)
-        return fail(AA_ERR_ARG, "aa_scatter_samples: bad argument");
+        return fail(AA_ERR_ARG, "aa_scatter_samples_piece: bad argument");
     if (c->rank == root && !full_dev && n_samples > 0)
-        return fail(AA_ERR_ARG, "aa_scatter_samples: the root needs the whole buffer");
-    COMM_DEVICE(c, "aa_scatter_samples");
+        return fail(AA_ERR_ARG, "aa_scatter_samples_piece: the root needs the whole buffer");
+    COMM_DEVICE(c, "aa_scatter_samples_piece");
     const int64_t total = n_samples < n_fft ? 0 : (n_samples - n_fft) / hop + 1;
     int64_t f0, f1, s0, s1, a, b;
     frames_of(total, c->world, c->rank, &f0, &f1);
     samples_of(f0, f1, n_fft, hop, &s0, &s1);
     if (s1 - s0 > local_capacity || (s1 > s0 && !local_dev))
-        return fail(AA_ERR_LEN, "aa_scatter_samples: rank %d needs %lld samples, local buffer holds %lld",
+        return fail(AA_ERR_LEN, "aa_scatter_samples_piece: rank %d needs %lld samples, local buffer holds %lld",
                     c->rank, (long long)(s1 - s0), (long long)local_capacity);
     piece_samples_of(f0, f1, n_pieces, piece, n_fft, hop, &a, &b);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -325,7 +328,7 @@ int aa_scatter_samples_piece(aa_comm *c, const float *full_dev, int64_t n_sample
             hipError_t e = hipMemcpyAsync(local_dev + (a - s0), full_dev + a, sizeof(float) * (size_t)(b - a),
                                           hipMemcpyDeviceToDevice, st);
             if (e != hipSuccess)
-                return fail(AA_ERR_HIP, "aa_scatter_samples: %s", hipGetErrorString(e));
+                return fail(AA_ERR_HIP, "aa_scatter_samples_piece: %s", hipGetErrorString(e));
         }
         GroupScope grp;
         NCCL_TRY(grp.begin());
@@ -356,21 +359,21 @@ int aa_gather_rows_piece(aa_comm *c, const float *rows_dev, int64_t total_frames
 {
     if (!c || total_frames < 0 || cols <= 0 || root < -1 || root >= c->world || n_pieces <= 0 || piece < 0 ||
         piece >= n_pieces)
-        return fail(AA_ERR_ARG, "aa_gather_rows: bad argument");
-    COMM_DEVICE(c, "aa_gather_rows");
+        return fail(AA_ERR_ARG, "aa_gather_rows_piece: bad argument");
+    COMM_DEVICE(c, "aa_gather_rows_piece");
     int64_t f0, f1, p0, p1;
     frames_of(total_frames, c->world, c->rank, &f0, &f1);
     piece_of(f0, f1, n_pieces, piece, &p0, &p1);
     const bool receiver = root < 0 || root == c->rank;
     if ((f1 > f0 && !rows_dev) || (receiver && total_frames > 0 && !out_dev))
-        return fail(AA_ERR_ARG, "aa_gather_rows: NULL buffer");
+        return fail(AA_ERR_ARG, "aa_gather_rows_piece: NULL buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *mine = rows_dev + (p0 - f0) * cols;           // rows_dev holds the rank's whole range
     if (receiver && p1 > p0 && mine != out_dev + p0 * cols) {
         hipError_t e = hipMemcpyAsync(out_dev + p0 * cols, mine, sizeof(float) * (size_t)((p1 - p0) * cols),
                                       hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess)
-            return fail(AA_ERR_HIP, "aa_gather_rows: %s", hipGetErrorString(e));
+            return fail(AA_ERR_HIP, "aa_gather_rows_piece: %s", hipGetErrorString(e));
     }
     if (c->world == 1)
         return AA_OK;
@@ -451,37 +454,55 @@ int aa_sharded_pipeline(aa_comm *cin, aa_comm *cout, const float *full_dev, int6
     hipStream_t st = static_cast<hipStream_t>(stream), sin = cin->side, sout = cout->side;
     hipEvent_t *ev = cin->events.data();        // [0] fork, [1 + k] samples of piece k landed, [1 + P + k] rows of piece k computed,
                                                 // [1 + 2 P] last gather issued
+    // From here on no early return: every failure goes through the join at the bottom, and a failure of the COMPUTE side
+    // (the callback, an event call) does not stop this rank's remaining exchanges - its peers' matching sends / receives
+    // are already queued or about to be, and a rank that stopped posting would leave them waiting in RCCL for ever.  The
+    // rows of the pieces behind such a failure are undefined; the first error is what the call returns.  A failure of an
+    // exchange itself (AA_ERR_NCCL, or HIP inside one) ends the posting: the communicators are then unusable and must
+    // be destroyed (include/aa_stft.h says so).
+    int rc_first = AA_OK;
+    std::string first_msg;
+    auto note = [&](int r) {
+        if (r != AA_OK && rc_first == AA_OK) {
+            rc_first = r;
+            first_msg = aa_last_error();
+        }
+        return r;
+    };
+    auto hip_ok = [&](hipError_t e) {
+        if (e != hipSuccess)
+            note(fail(AA_ERR_HIP, "aa_sharded_pipeline: %s", hipGetErrorString(e)));
+        return e == hipSuccess;
+    };
     // fork: both exchange streams start behind whatever the caller queued on `stream` (the producer of full_dev)
-    HIP_TRY(hipEventRecord(ev[0], st), "aa_sharded_pipeline");
-    HIP_TRY(hipStreamWaitEvent(sin, ev[0], 0), "aa_sharded_pipeline");
-    if (sout != sin)
-        HIP_TRY(hipStreamWaitEvent(sout, ev[0], 0), "aa_sharded_pipeline");
+    bool forked = hip_ok(hipEventRecord(ev[0], st)) && hip_ok(hipStreamWaitEvent(sin, ev[0], 0)) &&
+                  (sout == sin || hip_ok(hipStreamWaitEvent(sout, ev[0], 0)));
     auto scatter = [&](int k) -> int {
         int r = aa_scatter_samples_piece(cin, full_dev, n_samples, n_fft, hop, root, local_dev, local_capacity, P, k, sin);
         if (r != AA_OK)
             return r;
-        HIP_TRY(hipEventRecord(ev[1 + k], sin), "aa_sharded_pipeline");
+        hip_ok(hipEventRecord(ev[1 + k], sin));
         return AA_OK;
     };
     // The issue order is the same on every rank - S0, S1, [C0], G0, S2, [C1], G1, .. - which is what RCCL asks of
     // operations on one communicator (cin == cout) and of the two directions of a pair of ranks.
-    rc = scatter(0);
-    for (int k = 0; k < P && rc == AA_OK; ++k) {
-        if (k + 1 < P)
-            rc = scatter(k + 1);
-        if (rc != AA_OK)
+    bool exchange_ok = forked;
+    if (exchange_ok)
+        exchange_ok = note(scatter(0)) == AA_OK;
+    for (int k = 0; k < P && exchange_ok; ++k) {
+        if (k + 1 < P && note(scatter(k + 1)) != AA_OK) {
+            exchange_ok = false;
             break;
+        }
         int64_t p0, p1;
         piece_of(f0, f1, P, k, &p0, &p1);
-        HIP_TRY(hipStreamWaitEvent(st, ev[1 + k], 0), "aa_sharded_pipeline");
-        if (p1 > p0) {
-            rc = compute(user, p0 - f0, p1 - f0, stream);          // frames relative to the rank's range, as local_dev / rows_dev are
-            if (rc != AA_OK)
-                break;
-        }
-        HIP_TRY(hipEventRecord(ev[1 + P + k], st), "aa_sharded_pipeline");
-        HIP_TRY(hipStreamWaitEvent(sout, ev[1 + P + k], 0), "aa_sharded_pipeline");
-        rc = aa_gather_rows_piece(cout, rows_dev, total, cols, root, out_dev, P, k, sout);
+        hip_ok(hipStreamWaitEvent(st, ev[1 + k], 0));
+        if (p1 > p0 && rc_first == AA_OK)
+            note(compute(user, p0 - f0, p1 - f0, stream));       // frames relative to the rank's range, as local_dev / rows_dev are
+        hip_ok(hipEventRecord(ev[1 + P + k], st));
+        hip_ok(hipStreamWaitEvent(sout, ev[1 + P + k], 0));
+        if (note(aa_gather_rows_piece(cout, rows_dev, total, cols, root, out_dev, P, k, sout)) != AA_OK)
+            exchange_ok = false;                                  // (an exchange failed: stop posting)
     }
     // join: `stream` continues behind the last gather (and, through it, behind everything the pipeline queued) -
     // also on an error path, so that nothing the caller queues next overtakes what was already issued
@@ -491,7 +512,7 @@ int aa_sharded_pipeline(aa_comm *cin, aa_comm *cout, const float *full_dev, int6
         (void)hipEventRecord(ev[0], sin);
         (void)hipStreamWaitEvent(st, ev[0], 0);
     }
-    return rc;
+    return rc_first == AA_OK ? AA_OK : fail(rc_first, "%s", first_msg.c_str());
 }
 
 }  // extern "C"

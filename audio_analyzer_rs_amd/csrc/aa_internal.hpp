@@ -279,3 +279,7 @@ hipError_t launch_flux_div3_check(uint32_t first, uint64_t n, unsigned long long
 hipError_t launch_stream_copy(const float *src, float *dst, int64_t n_floats, int writes, hipStream_t stream);
 
 }  // namespace aa
+
+// the HIP device a communicator was created on (aa_comm.cpp; internal: aa_stft_execute_sharded checks it against its plan's)
+struct aa_comm;
+int aa_comm_device_index(const aa_comm *comm);

@@ -50,10 +50,17 @@ def decode_samples(raw, fmt, bits):
     if fmt == _PCM and bits == 16:
         return decode_pcm16(np.frombuffer(raw, dtype="<i2"))
     if fmt == _PCM and bits == 24:
-        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
-        q = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        q = np.where(q >= 1 << 23, q - (1 << 24), q)                     # sign extension
-        return (q.astype(np.float64) / 8388608.0).astype(np.float32)
+        # the three bytes into the upper three of a little-endian int32, an arithmetic shift for the sign; in pieces, so
+        # that an hour of audio (518 MB of samples) needs the output and one piece of temporaries, not ~30 B per sample
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3)
+        out = np.empty(b.shape[0], dtype=np.float32)
+        step = 1 << 22
+        for lo in range(0, b.shape[0], step):
+            piece = b[lo:lo + step]
+            q = np.zeros((piece.shape[0], 4), dtype=np.uint8)
+            q[:, 1:] = piece
+            out[lo:lo + step] = ((q.view("<i4")[:, 0] >> 8).astype(np.float64) / 8388608.0).astype(np.float32)
+        return out
     if fmt == _PCM and bits == 32:
         return (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
     if fmt == _FLOAT and bits == 32:
@@ -89,7 +96,7 @@ def read_wav(path):
         elif tag == b"data":
             if fmt is None:
                 raise ValueError(f"{path}: data chunk in front of the fmt chunk")
-            if ch < 1 or bits % 8 or align != ch * bits // 8:
+            if ch < 1 or bits < 8 or bits % 8 or align != ch * bits // 8:
                 raise ValueError(f"{path}: inconsistent fmt chunk ({ch} channels, {bits} bits, block align {align})")
             whole = len(body) - len(body) % align                      # (a truncated last frame is dropped)
             x = decode_samples(body[:whole], fmt, bits)

@@ -539,7 +539,7 @@ def run_single(args):
         detail["configs"] = result["configs"]
         for k, rec in result["configs"].items():
             for ek in ("err", "err_sine", "err_chirp"):
-                if ek in rec and not rec[ek] <= (2e-5 if "logmel" in k else 1e-5):
+                if ek in rec and not rec[ek] <= 1e-5:
                     ok = False
                     print(f"post-check FAILED: configs[{k}].{ek} = {rec[ek]}", file=sys.stderr)
     if not args.skip_cpu:

@@ -509,7 +509,12 @@ int aa_gather_rows_piece(aa_comm *comm, const float *rows_dev, int64_t total_fra
  * and `stream` continues behind the last gather.  `compute(user, frame_begin, frame_end, stream)` must queue the
  * transform of local frames [frame_begin, frame_end) - relative to the rank's range, as local_dev and rows_dev are
  * - on `stream` and return AA_OK; it is called once per non-empty piece, in order.  One pipeline at a time per
- * communicator.  Every rank issues S0, S1, G0, S2, G1, ... in this order (what RCCL requires of one communicator). */
+ * communicator.  Every rank issues S0, S1, G0, S2, G1, ... in this order (what RCCL requires of one communicator).
+ * Errors: a failure of the compute side (the callback, an event call) on one rank does NOT stop that rank's remaining
+ * exchanges - its peers' matching sends / receives would otherwise wait for ever; the rows of the pieces behind the
+ * failure are undefined and the first error is returned.  A failed exchange (AA_ERR_NCCL, or a HIP error inside one)
+ * ends the posting; the communicators are unusable afterwards and must be destroyed.  Either way `stream` is joined
+ * behind everything that was queued. */
 typedef int (*aa_piece_fn)(void *user, int64_t frame_begin, int64_t frame_end, void *stream);
 int aa_sharded_pipeline(aa_comm *comm_in, aa_comm *comm_out, const float *full_dev, int64_t n_samples,
                         int32_t n_fft, int32_t hop, int32_t cols, int32_t root, float *local_dev,
@@ -518,7 +523,10 @@ int aa_sharded_pipeline(aa_comm *comm_in, aa_comm *comm_out, const float *full_d
 /* aa_sharded_pipeline with aa_stft_execute_device of `plan` as the compute: rank `root`'s samples in, the dense
  * [total_frames][cols] slab on `root` out.  local_dev: the rank's sample range (capacity in floats), rows_dev its
  * [f1 - f0][cols] rows; on the root local_dev may be full_dev + s0 and rows_dev its slice of out_dev (no copies).
- * The plan, both communicators and `stream` belong to one device. */
+ * The plan, both communicators and `stream` belong to one device (AA_ERR_ARG if the plan's and the communicators'
+ * differ); local_dev - and rows_dev of a log-mel / MFCC plan - must be 16-byte aligned (AA_ERR_ARG otherwise: from an
+ * odd sample buffer the pieces would take the generic kernels and the rows would no longer be bit-equal to the
+ * unsharded launch). */
 int aa_stft_execute_sharded(aa_stft_plan *plan, aa_comm *comm_in, aa_comm *comm_out, const float *full_dev,
                             int64_t n_samples, int32_t root, float *local_dev, int64_t local_capacity,
                             float *rows_dev, float *out_dev, int32_t n_pieces, void *stream);

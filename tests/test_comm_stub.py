@@ -410,6 +410,49 @@ for world in (2, 3, 8):
             for b in local + rows + [out]:
                 b.free()
             checked += 1
+        # (D) a compute callback that FAILS on one rank (its second non-empty piece): that rank still posts every exchange -
+        # its peers' matching receives would otherwise wait in RCCL for ever -, the call returns the callback's code with
+        # `stream` joined, the pieces of the other ranks arrive as they should
+        bad = order[-1]
+        if len([1 for k in range(P) if shard_piece(*frames[bad], P, k)[1] > shard_piece(*frames[bad], P, k)[0]]) >= 2:
+            stub.aa_stub_reset()
+            local = [Dev(s1 - s0 + 3) for s0, s1 in ranges]
+            rows = [Dev((f1 - f0) * cols, np.zeros((f1 - f0) * cols, np.float32)) for f0, f1 in frames]
+            out = Dev(total_frames * cols, np.zeros(total_frames * cols, np.float32))
+            seen = {r: 0 for r in range(world)}
+            rcs, counts = {}, {}
+            for r in order:
+                def compute(user, fb, fe, stream, r=r):
+                    hip.hipDeviceSynchronize()
+                    seen[r] += 1
+                    if r == bad and seen[r] == 2:
+                        return -5
+                    assert not (r == bad and seen[r] > 2), "compute called again behind its own failure"
+                    loc = local[r].get()
+                    part = np.stack([2.0 * loc[i * HOP + 3 * np.arange(cols)] + 1.0 for i in range(fb, fe)]).astype(np.float32)
+                    assert hip.hipMemcpy(rows[r].ptr + 4 * fb * cols, part.ctypes.data, 4 * part.size, 1) == 0
+                    return 0
+                n0 = stub.aa_stub_log_count()
+                rcs[r] = lib.aa_sharded_pipeline(comms[r], comms[r], full.ptr if r == root else None, n_samples, N, HOP, cols, root,
+                                                 local[r].ptr, local[r].n, rows[r].ptr if rows[r].n else None,
+                                                 out.ptr if r == root and out.n else None, P, PIECE_FN(compute), None, None)
+                counts[r] = stub.aa_stub_log_count() - n0
+            hip.hipDeviceSynchronize()
+            L = log()
+            quiet(); pairs_up(L)                                     # every send has met its receive: nobody is left waiting
+            assert rcs[bad] == -5 and all(rc == 0 for r, rc in rcs.items() if r != bad), rcs
+            expect = np.stack([2.0 * x[g * HOP + 3 * np.arange(cols)] + 1.0 for g in range(total_frames)]).astype(np.float32)
+            got = out.get().reshape(-1, cols)
+            for r in range(world):
+                f0, f1 = frames[r]
+                if r != bad:
+                    assert np.array_equal(got[f0:f1], expect[f0:f1]), (world, r)
+                else:
+                    q0, q1 = [shard_piece(f0, f1, P, k) for k in range(P) if shard_piece(f0, f1, P, k)[1] > shard_piece(f0, f1, P, k)[0]][0]
+                    assert np.array_equal(got[q0:q1], expect[q0:q1])     # (the piece in front of the failure)
+            for b in local + rows + [out]:
+                b.free()
+            checked += 1
         full.free()
     # argument checks: a piece index out of range, communicators of different ranks
     assert lib.aa_scatter_samples_piece(comms[0], None, 0, N, HOP, 0, None, 0, 4, 4, None) == -1
@@ -447,10 +490,15 @@ def run_child(tmp_path, host_hip):
     return int(r.stdout.split()[-1])
 
 
+# per world: 4 whole-range cases x (2 + 2 x 3 sub-scenarios) + 6 piece cases x 2 pipelines, + (r5) the failing-callback
+# pipeline in the piece cases that leave the failing rank two non-empty pieces (3 per world)
+N_SCENARIOS = 3 * (4 * (2 + 2 * 3) + 6 * 2) + 9
+
+
 def test_comm_call_lists_worlds_2_3_8_host(tmp_path):
-    assert run_child(tmp_path, host_hip=True) == 3 * (4 * (2 + 2 * 3) + 6 * 2)
+    assert run_child(tmp_path, host_hip=True) == N_SCENARIOS
 
 
 @pytest.mark.gpu
 def test_comm_call_lists_worlds_2_3_8_device_buffers(tmp_path):
-    assert run_child(tmp_path, host_hip=False) == 3 * (4 * (2 + 2 * 3) + 6 * 2)
+    assert run_child(tmp_path, host_hip=False) == N_SCENARIOS

@@ -494,9 +494,18 @@ def test_wav_reader_other_sample_formats(tmp_path):
     (tmp_path / "alaw.wav").write_bytes(riff(fmt_chunk(6, 1, 8000, 8), b"\x00" * 16))
     (tmp_path / "bad.wav").write_bytes(b"RIFX" + b"\x00" * 40)
     (tmp_path / "nodata.wav").write_bytes(b"RIFF" + struct.pack("<I", 28) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt_chunk(1, 1, 8000, 16))
-    for bad in ("alaw.wav", "bad.wav", "nodata.wav"):
+    # (a fmt chunk that says 0 bits / block align 0 must be refused as inconsistent, not divide by zero)
+    (tmp_path / "zerobits.wav").write_bytes(riff(struct.pack("<HHIIHH", 1, 1, 8000, 0, 0, 0), b"\x00" * 16))
+    for bad in ("alaw.wav", "bad.wav", "nodata.wav", "zerobits.wav"):
         with pytest.raises(ValueError):
             aa.wav.read_wav(tmp_path / bad)
+    # 24-bit decoding runs in pieces of 2^22 samples: a file longer than one piece, every sample checked
+    big = (np.arange(-(1 << 22) - 5, (1 << 22) + 6, dtype=np.int64) % (1 << 24)).astype(np.int64)
+    big = np.where(big >= 1 << 23, big - (1 << 24), big).astype(np.int32)
+    raw24 = (big.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]).tobytes()
+    (tmp_path / "big24.wav").write_bytes(riff(fmt_chunk(1, 1, 48000, 24), raw24))
+    y, _ = aa.wav.read_wav(tmp_path / "big24.wav")
+    assert np.array_equal(y, (big.astype(np.float64) / 8388608.0).astype(np.float32))
 
 
 def test_detector_restatements_vs_golden(oracle_mod):
