@@ -192,6 +192,9 @@ SIGNATURES = {
     "aa_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_stream_push": (ctypes.c_int, [ctypes.c_void_p, _f32p, ctypes.c_int32, _f32p, _i64p,
                                       ctypes.c_int64, _i64p]),
+    "aa_rows_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    "aa_rows_free": (ctypes.c_int, [ctypes.c_void_p]),
     "aa_diag_flux_div3_device": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "aa_diag_stream_copy_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                                   ctypes.c_void_p]),

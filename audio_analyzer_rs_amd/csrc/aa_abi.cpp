@@ -1561,6 +1561,135 @@ int aa_host_unregister(void *ptr)
     return AA_OK;
 }
 
+// ----------------------------------------------------- rows placed by measurement --
+// process_forward's own rows (AA_OUT_COMPLEX, fft.rs:33-35) leave the 1024 / 256 launch at ~6.4 TB/s into some output
+// buffers and ~5.1 TB/s into others - a property of the PHYSICAL memory behind the buffer, for the buffer's lifetime.
+// r5 (profiles/r05_rows_scan_complex.txt, r05_rows_contrast.txt): of 465 slabs of 462 MB that tile 200 GiB of one
+// device, 22 are fast (95 us), in runs of neighbouring slabs; into a fast and a slow slab of one process the launch
+// issues the same 7.49 M write requests of the same sizes, and in the slow one the L2 waits 1.44 x as long for DRAM
+// write credits and a request stays outstanding 9 % longer - the memory side drains these 1024 concurrent row streams
+// less efficiently from some physical regions than from others.  Nothing a kernel or a virtual address can steer; so
+// the library does what it can: take slab after slab (all held, so each is other physical memory), time the plan's own
+// launch into each, stop at the first that is clearly faster than the others, free the rest.
+namespace {
+float time_launches(aa_stft_plan *p, const float *samples, int64_t n_samples, int64_t n_frames, float *rows, int warm,
+                    int timed, hipEvent_t e0, hipEvent_t e1, int &rc)
+{
+    for (int i = 0; i < warm + timed && rc == AA_OK; ++i) {
+        if (i == warm && hipEventRecord(e0, nullptr) != hipSuccess)
+            rc = fail(AA_ERR_HIP, "aa_rows_alloc: hipEventRecord");
+        if (rc == AA_OK)
+            rc = aa_stft_execute_device(p, samples, n_samples, 0, n_frames, rows, nullptr);
+    }
+    float ms = 0.0f;
+    if (rc == AA_OK && (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                        hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+        rc = fail(AA_ERR_HIP, "aa_rows_alloc: timing a candidate failed");
+    return ms * 1e3f / (float)timed;
+}
+}  // namespace
+
+int aa_rows_alloc(aa_stft_plan *p, int64_t n_frames, int32_t n_candidates, float **out_rows_dev, float *kept_us,
+                  float *typical_us)
+{
+    if (!p || !out_rows_dev || n_frames < 0 || n_candidates < 1 || n_candidates > 4096)
+        return fail(AA_ERR_ARG, "aa_rows_alloc: bad argument (1..4096 candidates)");
+    *out_rows_dev = nullptr;
+    if (kept_us)
+        *kept_us = 0.0f;
+    if (typical_us)
+        *typical_us = 0.0f;
+    aa::DeviceGuard guard(p->device);
+    if (!guard.ok)
+        return fail(AA_ERR_HIP, "aa_rows_alloc: cannot select device %d", p->device);
+    const size_t bytes = sizeof(float) * (size_t)(n_frames > 0 ? n_frames : 1) * (size_t)p->out_cols;
+    if (n_candidates == 1 || n_frames == 0) {
+        AA_HIP(hipMalloc(reinterpret_cast<void **>(out_rows_dev), bytes));
+        return AA_OK;
+    }
+    const int64_t n_samples = (n_frames - 1) * (int64_t)p->cfg.hop + p->cfg.n_fft;
+    std::vector<float *> cand;
+    std::vector<float> us;
+    float *samples = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&samples), sizeof(float) * (size_t)n_samples);
+    // (any finite samples will do: the launch has no data-dependent path; 0x3C3C3C3C is 0.0115)
+    if (err == hipSuccess)
+        err = hipMemset(samples, 0x3C, sizeof(float) * (size_t)n_samples);
+    if (err == hipSuccess)
+        err = hipEventCreate(&e0);
+    if (err == hipSuccess)
+        err = hipEventCreate(&e1);
+    int rc = err == hipSuccess ? AA_OK : fail(AA_ERR_HIP, "aa_rows_alloc: %s", hipGetErrorString(err));
+    auto median = [&]() {
+        std::vector<float> v(us);
+        std::nth_element(v.begin(), v.begin() + (long)(v.size() / 2), v.end());
+        return v[v.size() / 2];
+    };
+    int kept = -1;
+    while (rc == AA_OK && (int)cand.size() < n_candidates) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t(2) << 30))
+            break;                                   // (leave the device two GiB: choose among what there is)
+        float *slab = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&slab), bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        cand.push_back(slab);
+        if (cand.size() == 1)                        // the clocks up before anything is compared
+            (void)time_launches(p, samples, n_samples, n_frames, slab, 0, 60, e0, e1, rc);
+        us.push_back(time_launches(p, samples, n_samples, n_frames, slab, 2, 6, e0, e1, rc));
+        if (rc != AA_OK || us.size() < 6)
+            continue;
+        const float med = median();
+        if (us.back() < 0.90f * med) {
+            // confirm against the slab nearest the median before the search ends on it
+            size_t ref = 0;
+            for (size_t i = 0; i + 1 < us.size(); ++i)
+                ref = std::fabs(us[i] - med) < std::fabs(us[ref] - med) ? i : ref;
+            const float a = time_launches(p, samples, n_samples, n_frames, slab, 2, 16, e0, e1, rc);
+            const float b = time_launches(p, samples, n_samples, n_frames, cand[ref], 2, 16, e0, e1, rc);
+            us.back() = a;
+            if (rc == AA_OK && a < 0.92f * b) {
+                kept = (int)cand.size() - 1;
+                break;
+            }
+        }
+    }
+    if (rc == AA_OK && cand.empty())
+        rc = fail(AA_ERR_NOMEM, "aa_rows_alloc: no candidate slab could be allocated");
+    if (rc == AA_OK) {
+        if (kept < 0) {                              // no region stands out: the fastest of what was seen
+            kept = 0;
+            for (size_t c = 1; c < us.size(); ++c)
+                kept = us[c] < us[(size_t)kept] ? (int)c : kept;
+        }
+        *out_rows_dev = cand[(size_t)kept];
+        if (kept_us)
+            *kept_us = us[(size_t)kept];
+        if (typical_us)
+            *typical_us = median();
+    }
+    for (size_t c = 0; c < cand.size(); ++c)
+        if (rc != AA_OK || (int)c != kept)
+            (void)hipFree(cand[c]);
+    if (samples)
+        (void)hipFree(samples);
+    if (e0)
+        (void)hipEventDestroy(e0);
+    if (e1)
+        (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int aa_rows_free(float *rows_dev)
+{
+    if (rows_dev)
+        AA_HIP(hipFree(rows_dev));
+    return AA_OK;
+}
+
 // ----------------------------------------------------------------------- downmix --
 int aa_downmix_device(const float *interleaved_dev, int64_t n_frames, int32_t channels,
                       float *mono_dev, void *stream)

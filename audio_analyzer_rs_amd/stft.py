@@ -26,6 +26,24 @@ def _current_device_index():
         return 0
 
 
+class _RowsHolder:
+    """Owner of an aa_rows_alloc buffer, seen by torch through __cuda_array_interface__ (torch keeps the holder alive for
+    as long as a tensor views the memory; the buffer goes back with the holder)."""
+
+    def __init__(self, lib, ptr, shape):
+        self._lib, self._ptr = lib, ptr
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2,
+                                         "strides": None}
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.aa_rows_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+
 class Stft:
     def __init__(self, n_fft, hop=None, window="hann", output="mag", sample_rate=48000,
                  n_mels=128, n_mfcc=40, fmin=0.0, fmax=0.0, log_floor=0.0):
@@ -66,6 +84,21 @@ class Stft:
     def num_frames(self, n_samples):
         """floor((L - N)/hop) + 1 (stft.rs:273, 436-437); integer-exact."""
         return int(self._lib.aa_stft_num_frames(self._plan, int(n_samples)))
+
+    def alloc_rows(self, n_frames, candidates=128):
+        """A CUDA float32 row buffer [n_frames, cols] placed by measurement (aa_rows_alloc: slab after slab - up to
+        `candidates` - with the plan's launch timed into each, until one is clearly faster than the others) - for the
+        complex rows, whose launch time depends on the physical memory behind the buffer.  candidates = 1: a plain
+        allocation.  Returns (tensor, kept_us, typical_us); the memory is released with the tensor."""
+        import torch
+
+        ptr = ctypes.c_void_p()
+        kept, typical = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        _lib.check(self._lib.aa_rows_alloc(self._plan, int(n_frames), int(candidates), ctypes.byref(ptr),
+                                           ctypes.byref(kept), ctypes.byref(typical)))
+        holder = _RowsHolder(self._lib, ptr.value, (int(n_frames), self.cols))
+        t = torch.as_tensor(holder, device=torch.device("cuda", self.device_index))
+        return t, float(kept.value), float(typical.value)
 
     def _wrap(self, flat, nf):
         if self.output == "complex":

@@ -280,9 +280,26 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     out = {}
 
     def geometry(key, n_fft, hop, kind, bytes_per_frame, xin=xd, xhost=x, **kw):
+        placed = kw.pop("placed", False)
         plan = aa.Stft(n_fft, hop, output=kind, **kw)
         nf = plan.num_frames(xin.shape[0])
-        buf = torch.empty((nf, plan.cols), dtype=torch.float32, device=dev)
+        extra = {}
+        if placed:
+            # the rows placed by measurement (aa_rows_alloc: the complex launch's time depends on the physical memory
+            # behind its output) - the product's recommended allocation for this output kind; the
+            # same launch into an ordinary allocation is timed next to it
+            plain = torch.empty((nf, plan.cols), dtype=torch.float32, device=dev)
+            timer.settle(lambda: plan.execute_device(xin, 0, nf, out=plain, stream=st))
+            ms_plain, _ = timer.time(lambda: plan.execute_device(xin, 0, nf, out=plain, stream=st), steps, warmup)
+            del plain
+            t_alloc = time.perf_counter()
+            buf, kept_us, typical_us = plan.alloc_rows(nf, candidates=256)
+            extra = {"rows": "aa_rows_alloc", "ms_plain_alloc": r4(ms_plain), "alloc_s": r4(time.perf_counter() - t_alloc),
+                     "alloc_kept_us": r4(kept_us), "alloc_typical_us": r4(typical_us),
+                     "frac_plain_alloc": r4(bytes_per_frame * nf / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+            buf = buf.view(nf, plan.cols)
+        else:
+            buf = torch.empty((nf, plan.cols), dtype=torch.float32, device=dev)
 
         def step():
             plan.execute_device(xin, 0, nf, out=buf, stream=st)
@@ -291,6 +308,7 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
         ms, _ = timer.time(step, steps, warmup)
         rec = {"kernel": plan.kernel, "frames": nf, "ms": r4(ms), "B_per_frame": bytes_per_frame,
                "frac": r4(bytes_per_frame * nf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)}
+        rec.update(extra)
         if kind in ("mag", "complex"):
             ids = pick_rows(nf, 64, seed=n_fft)
             rows = buf[torch.from_numpy(ids).to(dev)].cpu().numpy()
@@ -304,7 +322,7 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
     # the reference's own geometries and process_forward's real output format
     geometry("mag_2048_512", 2048, 512, "mag", 512 * 4 + 1025 * 4)
     geometry("mag_256_64", 256, 64, "mag", 64 * 4 + 129 * 4)
-    geometry("complex_1024_256", 1024, 256, "complex", 256 * 4 + 513 * 8)
+    geometry("complex_1024_256", 1024, 256, "complex", 256 * 4 + 513 * 8, placed=True)
 
     # configs[2]: 2048-pt + 128 log-mel on synthetic stereo (two channels, seeds 12345 / 54321)
     n_mels = 128

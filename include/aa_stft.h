@@ -192,6 +192,23 @@ int aa_stft_execute_channels_device(aa_stft_plan *plan, const float *samples_dev
 int aa_stft_execute_host(aa_stft_plan *plan, const float *samples_host, int64_t n_samples,
                          float *out_host);
 
+/* A row buffer for `plan`, n_frames * aa_stft_out_cols floats of device memory, PLACED BY MEASUREMENT.  Why:
+ * process_forward's own rows (AA_OUT_COMPLEX, fft.rs:33-35) stream out of the 1024 / 256 launch at ~6.4 TB/s into some
+ * buffers and ~5.1 TB/s into others (89-95 us against 118 us for ten minutes of audio) - a property of the PHYSICAL
+ * memory behind the buffer that lasts the buffer's lifetime: about one 462-MB slab in twenty of a device is fast, in
+ * runs of neighbours; same write requests, the DRAM side returns write credits 1.4 x more slowly in the others
+ * (DESIGN.md section 5).  No virtual address or kernel parameter reaches that, so: slab after slab is allocated (all
+ * held meanwhile, so that each is other physical memory) and the plan's own launch timed into it (a few launches on
+ * the default stream, on scratch samples) until one is clearly faster than the median of those seen (re-timed to
+ * confirm) or max_candidates slabs / the device's free memory less 2 GiB are used up - then the fastest seen is kept;
+ * the rest is freed.  The magnitude rows do not take part (every slab within 2 %): for them, or with max_candidates
+ * = 1, this is a plain allocation.  kept_us / typical_us (nullable): the launch time into the kept slab and the median
+ * over the slabs tried.  Synchronous; typically 10-60 slabs and well under a second, transiently that many x the
+ * buffer.  Release with aa_rows_free. */
+int aa_rows_alloc(aa_stft_plan *plan, int64_t n_frames, int32_t max_candidates, float **out_rows_dev, float *kept_us,
+                  float *typical_us);
+int aa_rows_free(float *rows_dev);
+
 /* Page-lock / release a caller-owned host buffer (hipHostRegister).  With BOTH buffers of
  * aa_stft_execute_host registered, the call streams frame chunks over two HIP streams (H2D,
  * kernel, D2H overlapped) instead of staging through pageable copies.  The caller must

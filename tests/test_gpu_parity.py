@@ -644,6 +644,33 @@ def test_flux_div3_exhaustive(aa):
     assert total == 0
 
 
+def test_rows_alloc(aa, torch_mod):
+    """aa_rows_alloc: a row buffer placed by measurement (the complex rows' launch time depends on the physical memory
+    behind the buffer) is an ordinary buffer for every launch - same rows as a torch allocation, for one and for several
+    candidates, for a magnitude plan too; it goes back with the tensor; bad arguments are refused."""
+    import ctypes
+
+    x = aa.signals.synth_corpus(3, 1024 + 4999 * 256)
+    xd = torch_mod.from_numpy(x).cuda()
+    for kind in ("complex", "mag"):
+        plan = aa.Stft(1024, 256, output=kind)
+        nf = plan.num_frames(len(x))
+        want = plan(xd)
+        for cands in (1, 3, 40):
+            rows, kept_us, typical_us = plan.alloc_rows(nf, candidates=cands)
+            assert rows.shape == (nf, plan.cols) and rows.is_cuda and rows.dtype == torch_mod.float32
+            assert (kept_us > 0 and typical_us >= kept_us * 0.5) or cands == 1
+            rows.fill_(float("nan"))
+            plan.execute_device(xd, 0, nf, out=rows)
+            assert torch_mod.equal(rows.reshape(want.shape), want), (kind, cands)
+            del rows
+    lib = aa.load_library()
+    ptr = ctypes.c_void_p()
+    assert lib.aa_rows_alloc(plan._plan, 10, 0, ctypes.byref(ptr), None, None) == aa._lib.AA_ERR_ARG
+    assert lib.aa_rows_alloc(None, 10, 2, ctypes.byref(ptr), None, None) == aa._lib.AA_ERR_ARG
+    assert lib.aa_rows_free(None) == 0
+
+
 def test_diag_stream_copy(aa, torch_mod):
     """aa_diag_stream_copy_device (bench.py's measured ceiling): a copy and the twice-stored form move the bytes they
     claim to, for lengths around the workgroups' runs; bad arguments are refused."""
