@@ -1755,9 +1755,10 @@ int aa_diag_flux_div3_device(uint32_t first_bits, uint64_t count, uint64_t *mism
 int aa_diag_stream_copy_device(const float *src_dev, float *dst_dev, int64_t n_floats, int32_t writes_per_read,
                                void *stream)
 {
-    if (!src_dev || !dst_dev || n_floats < 0 || (n_floats & 3) || writes_per_read < 1 || writes_per_read > 2 ||
+    if (!src_dev || !dst_dev || n_floats < 0 || (n_floats & 3) ||
+        (writes_per_read != 1 && writes_per_read != 2 && writes_per_read != 4) ||
         ((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst_dev)) & 15u))
-        return fail(AA_ERR_ARG, "aa_diag_stream_copy_device: n_floats %% 4 == 0, 16-byte aligned buffers, 1 or 2 writes per read");
+        return fail(AA_ERR_ARG, "aa_diag_stream_copy_device: n_floats %% 4 == 0, 16-byte aligned buffers, 1, 2 or 4 writes per read");
     AA_HIP(aa::launch_stream_copy(src_dev, dst_dev, n_floats, writes_per_read, (hipStream_t)stream));
     return AA_OK;
 }

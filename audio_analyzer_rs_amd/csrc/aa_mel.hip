@@ -1537,9 +1537,12 @@ __global__ void downmix_stereo4_kernel(const dm4 *__restrict__ in, dm4 *__restri
 }
 
 // Diagnostics (include/aa_stft.h, aa_diag_stream_copy_device): the memory system's own ceiling for a launch's byte count,
-// measured with the product's access idiom and NO arithmetic - 16-byte nontemporal loads and stores, persistent
-// workgroups on contiguous runs.  WRITES = 1: a plain copy; WRITES = 2: every piece stored twice (dst[i], dst[n + i]),
-// the 1 : 2 read : write mix of the magnitude launch (hop floats in, ~2 hop floats out per frame).
+// measured with the product's access idiom and NO arithmetic - 16-byte loads, 16-byte nontemporal stores, persistent
+// workgroups on contiguous runs.  (Plain loads, as the product's LDS-DMA: a source that fits the 256-MB Infinity Cache
+// is then served from it launch after launch, like the product's 115 MB of samples - 6.5 TB/s for the 173-MB copy
+// where nontemporal loads, which pass the cache by, reach 5.1; tools/ubench_copy.hip, profiles/r05_ubench_copy.txt.)  WRITES = 1: a plain copy; WRITES = 2: every piece stored twice (dst[i], dst[n + i]),
+// the 1 : 2 read : write mix of the magnitude launch (hop floats in, ~2 hop floats out per frame); WRITES = 4: the 1 : 4
+// mix of the complex rows (hop floats in, 2 (n_fft / 2 + 1) out).
 template <int WRITES>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4)
 {
@@ -1550,19 +1553,19 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const v4f *__restrict_
         v4f r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            r[u] = __builtin_nontemporal_load(src + i + 256 * u);
+            r[u] = src[i + 256 * u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            __builtin_nontemporal_store(r[u], dst + i + 256 * u);
-            if (WRITES == 2)
-                __builtin_nontemporal_store(r[u], dst + n4 + i + 256 * u);
+#pragma unroll
+            for (int w = 0; w < WRITES; ++w)
+                __builtin_nontemporal_store(r[u], dst + w * n4 + i + 256 * u);
         }
     }
     for (; i < i1; i += 256) {
-        const v4f r = __builtin_nontemporal_load(src + i);
-        __builtin_nontemporal_store(r, dst + i);
-        if (WRITES == 2)
-            __builtin_nontemporal_store(r, dst + n4 + i);
+        const v4f r = src[i];
+#pragma unroll
+        for (int w = 0; w < WRITES; ++w)
+            __builtin_nontemporal_store(r, dst + w * n4 + i);
     }
 }
 
@@ -1572,7 +1575,8 @@ hipError_t launch_stream_copy(const float *src, float *dst, int64_t n_floats, in
 {
     if (n_floats <= 0)
         return hipSuccess;
-    if ((n_floats & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) || writes < 1 || writes > 2)
+    if ((n_floats & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) ||
+        (writes != 1 && writes != 2 && writes != 4))
         return hipErrorInvalidValue;
     const int64_t n4 = n_floats / 4;
     int64_t blocks = (n4 + 1023) / 1024;
@@ -1581,8 +1585,11 @@ hipError_t launch_stream_copy(const float *src, float *dst, int64_t n_floats, in
     if (writes == 1)
         hipLaunchKernelGGL(stream_copy_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream,
                            reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4);
-    else
+    else if (writes == 2)
         hipLaunchKernelGGL(stream_copy_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4);
+    else
+        hipLaunchKernelGGL(stream_copy_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream,
                            reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4);
     return hipGetLastError();
 }

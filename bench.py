@@ -237,37 +237,66 @@ def sustained_leg(timer, step, kernel_ms, seconds=2.0):
 
 def copy_ceiling(aa, torch, dev, timer, n_in, n_out):
     """What this box's memory system delivers for the launch's byte count with NO arithmetic, in the product's own access
-    idiom (aa_diag_stream_copy_device: 16-byte nontemporal loads and stores, persistent workgroups on contiguous runs):
+    idiom (aa_diag_stream_copy_device: 16-byte loads, 16-byte nontemporal stores, persistent workgroups on contiguous runs):
     (i) a plain copy of (in + out) / 2 floats (reads as many bytes as it writes), (ii) the launch's own 1 : 2 read :
     write mix (every input piece stored twice).  HIP events over 50 runs after a ramp, on the launch stream.
-    SURVEY.md section 8d: "report both nominal and measured-copy ceilings".  (Rounds 3-4 used torch's copy_, which
-    reaches 5.3-5.4 TB/s where the product's complex-row launch moves 6.4: a ceiling below the product is no ceiling.)"""
+    SURVEY.md section 8d: "report both nominal and measured-copy ceilings".
+    r5: a ceiling must not sit below what the product moves.  Rounds 3-4 used torch's copy_ into torch allocations
+    (5.3-5.4 TB/s where the product's complex-row launch moved 6.4): the write rate of this chip depends on the PHYSICAL
+    memory behind the destination (one 462-MB slab in twenty takes write streams ~25 % faster), so
+    the destinations here are placed by measurement (aa_rows_alloc, with the complex plan's launch as the probe) and the
+    same copies into ordinary allocations are reported next to them."""
     lib = aa.load_library()
     st = timer.stream.cuda_stream
     half = ((n_in + n_out) // 2) & ~3
     nin4 = n_in & ~3
     src = torch.empty(half, dtype=torch.float32, device=dev).normal_()
-    dst = torch.empty(half, dtype=torch.float32, device=dev)
     a = torch.empty(nin4, dtype=torch.float32, device=dev).normal_()
-    b = torch.empty(2 * nin4, dtype=torch.float32, device=dev)
+    probe = aa.Stft(N_FFT, HOP, output="complex")
+    rows_needed = -(-max(half, 4 * nin4) // probe.cols)
+    out = {}
+    for tag in ("placed", "plain"):
+        if tag == "placed":
+            slab, kept_us, typical_us = probe.alloc_rows(rows_needed, candidates=256)
+            slab = slab.view(-1)
+            out["placement_probe_us"] = [r4(kept_us), r4(typical_us)]
+        else:
+            slab = torch.empty(rows_needed * probe.cols, dtype=torch.float32, device=dev)
+        dst, b, b4 = slab[:half], slab[:2 * nin4], slab[:4 * nin4]
 
-    def copy():
-        aa._lib.check(lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), half, 1, st))
+        def copy():
+            aa._lib.check(lib.aa_diag_stream_copy_device(src.data_ptr(), dst.data_ptr(), half, 1, st))
 
-    def mix():
-        aa._lib.check(lib.aa_diag_stream_copy_device(a.data_ptr(), b.data_ptr(), nin4, 2, st))
+        def mix():
+            aa._lib.check(lib.aa_diag_stream_copy_device(a.data_ptr(), b.data_ptr(), nin4, 2, st))
 
-    timer.ramp(copy, 0.1)
-    ms_copy, _ = timer.time(copy, 50, 5)
-    timer.ramp(mix, 0.1)
-    ms_mix, _ = timer.time(mix, 50, 5)
-    torch.cuda.synchronize(dev)
-    ok = bool(torch.equal(dst, src)) and bool(torch.equal(b[:nin4], a)) and bool(torch.equal(b[nin4:], a))
-    del src, dst, a, b
-    return {"copy_GBps": 2 * half * 4 / (ms_copy * 1e-3) / 1e9, "mix_1r2w_GBps": 3 * nin4 * 4 / (ms_mix * 1e-3) / 1e9,
-            "copied_ok": ok,
-            "how": "aa_diag_stream_copy_device: dwordx4 nontemporal loads / stores, (in + out) / 2 floats copied; "
-                   "the input floats stored twice"}
+        def mix4():
+            aa._lib.check(lib.aa_diag_stream_copy_device(a.data_ptr(), b4.data_ptr(), nin4, 4, st))
+
+        timer.ramp(copy, 0.1)
+        ms_copy, _ = timer.time(copy, 50, 5)
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(dst, src))
+        timer.ramp(mix, 0.1)
+        ms_mix, _ = timer.time(mix, 50, 5)
+        torch.cuda.synchronize(dev)
+        ok = ok and bool(torch.equal(b[:nin4], a)) and bool(torch.equal(b[nin4:], a))
+        timer.ramp(mix4, 0.1)
+        ms_mix4, _ = timer.time(mix4, 50, 5)
+        torch.cuda.synchronize(dev)
+        ok = ok and all(bool(torch.equal(b4[w * nin4:(w + 1) * nin4], a)) for w in range(4))
+        out[tag] = {"copy_GBps": 2 * half * 4 / (ms_copy * 1e-3) / 1e9, "mix_1r2w_GBps": 3 * nin4 * 4 / (ms_mix * 1e-3) / 1e9,
+                    "mix_1r4w_GBps": 5 * nin4 * 4 / (ms_mix4 * 1e-3) / 1e9, "copied_ok": ok}
+        del dst, b, b4, slab
+    del src, a, probe
+    return {"copy_GBps": out["placed"]["copy_GBps"], "mix_1r2w_GBps": out["placed"]["mix_1r2w_GBps"],
+            "mix_1r4w_GBps": out["placed"]["mix_1r4w_GBps"],
+            "copied_ok": out["placed"]["copied_ok"] and out["plain"]["copied_ok"],
+            "plain_alloc": {"copy_GBps": r4(out["plain"]["copy_GBps"]), "mix_1r2w_GBps": r4(out["plain"]["mix_1r2w_GBps"]),
+                            "mix_1r4w_GBps": r4(out["plain"]["mix_1r4w_GBps"])},
+            "placement_probe_us": out["placement_probe_us"],
+            "how": "aa_diag_stream_copy_device: dwordx4 loads / nontemporal dwordx4 stores, (in + out) / 2 floats copied; "
+                   "the input floats stored twice; destinations placed by aa_rows_alloc (plain_alloc: torch allocations)"}
 
 
 def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
@@ -540,8 +569,10 @@ def run_single(args):
             "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": nf,
             # measured on this box, in this run (not a target: the nominal peak above stays `peak`)
             "copy_ceiling": {"copy_GBps": r4(ceil["copy_GBps"]), "mix_1r2w_GBps": r4(ceil["mix_1r2w_GBps"]),
+                             "mix_1r4w_GBps": r4(ceil["mix_1r4w_GBps"]),
                              "frac_of_copy": r4(achieved_gbs / ceil["copy_GBps"]),
                              "frac_of_mix": r4(achieved_gbs / ceil["mix_1r2w_GBps"]), "copied_ok": ceil["copied_ok"],
+                             "plain_alloc": ceil["plain_alloc"], "placement_probe_us": ceil["placement_probe_us"],
                              "how": ceil["how"]},
         },
         # >= 2 s of back-to-back launches of the same kernel between one pair of events

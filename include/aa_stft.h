@@ -554,10 +554,11 @@ int aa_stft_execute_sharded(aa_stft_plan *plan, aa_comm *comm_in, aa_comm *comm_
  * patterns from first_bits (count <= 2^32) and returns how many differ from the IEEE division (NaN == NaN):
  * tests/test_gpu_parity.py sweeps all 2^32 and expects 0.  Synchronous. */
 int aa_diag_flux_div3_device(uint32_t first_bits, uint64_t count, uint64_t *mismatches_host);
-/* What the memory system delivers with NO arithmetic, in the product's access idiom (16-byte nontemporal loads and
- * stores, persistent workgroups on contiguous runs): writes_per_read = 1 copies n_floats floats, = 2 stores every piece
- * twice (dst_dev holds 2 * n_floats: the 1 : 2 read : write mix of the magnitude launch).  n_floats % 4 == 0, both
- * buffers 16-byte aligned.  bench.py times it next to the headline kernel (roofline.copy_ceiling).  Asynchronous. */
+/* What the memory system delivers with NO arithmetic, in the product's access idiom (16-byte loads, 16-byte nontemporal
+ * stores, persistent workgroups on contiguous runs): writes_per_read = 1 copies n_floats floats, = 2 / 4 stores every
+ * piece two / four times (dst_dev holds that many x n_floats: the 1 : 2 read : write mix of the magnitude launch, the
+ * 1 : 4 mix of the complex rows).  n_floats % 4 == 0, both buffers 16-byte aligned.  bench.py times it next to the
+ * headline kernel (roofline.copy_ceiling).  Asynchronous. */
 int aa_diag_stream_copy_device(const float *src_dev, float *dst_dev, int64_t n_floats, int32_t writes_per_read,
                                void *stream);
 
