@@ -10,8 +10,8 @@ from ._lib import AaError, LIB_PATH  # noqa: F401
 from .fft import FftProcessor, hann_window  # noqa: F401
 from .stft import (Conditioner, PitchTracker, Stft, StftStream, downmix, global_floor_per_frame, onset_flux, onset_gates, pin, tuner_floor,  # noqa: F401
                    tuner_pitches, unpin)
-from .sharding import (Comm, ShardPlan, gather_rows, gather_samples, overlapped_e2e, piece_samples, scatter_samples,  # noqa: F401
-                       shard_frames, shard_piece, shard_samples)
+from .sharding import (Comm, IpcTransport, ShardPlan, gather_rows, gather_samples, overlap_counts, overlapped_e2e, piece_samples, scatter_samples,  # noqa: F401
+                       set_transport, shard_frames, shard_piece, shard_samples)
 from . import signals, theory, wav  # noqa: F401
 from .theory import Interval, MidiNote, Note, Tuner, TunerOutput  # noqa: F401
 

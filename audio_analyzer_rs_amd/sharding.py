@@ -101,6 +101,17 @@ def scatter_samples(full, shard, device=None, src=0):
     return local
 
 
+_TRANSPORT = None
+
+
+def set_transport(post):
+    """Replace torch.distributed's point-to-point calls in this module by `post(ops, group) -> requests` (ops =
+    [("send" | "recv", tensor, peer)], every request has .wait()); None restores batch_isend_irecv.  Used by the
+    one-GPU rehearsal of the sharded job (IpcTransport below)."""
+    global _TRANSPORT
+    _TRANSPORT = post
+
+
 def _p2p(ops):
     """Run a list of (kind, tensor, peer) point-to-point transfers as ONE grouped batch
     (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the GPU box)."""
@@ -108,9 +119,112 @@ def _p2p(ops):
 
     if not ops:
         return
+    if _TRANSPORT is not None:
+        for req in _TRANSPORT(ops, None):
+            req.wait()
+        return
     batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer) for kind, t, peer in ops]
     for req in dist.batch_isend_irecv(batch):
         req.wait()
+
+
+class IpcTransport:
+    """Point-to-point exchanges between ranks that SHARE ONE GPU, through device memory and with device-side ordering -
+    the rehearsal of the multi-GPU job on a one-GPU box (RCCL refuses two ranks on one device, and gloo would stage every
+    byte through the host).  The ranks rendezvous over a host-side process group (gloo); then
+
+      recv   the receiver publishes its destination (torch's IPC handle of the tensor: dmabuf under
+             HSA_ENABLE_IPC_MODE_LEGACY=0) to the sender;
+      send   the sender maps it, copies device-to-device on a side stream behind its own compute stream, records an
+             INTERPROCESS event behind the copy and tells the receiver which one;
+      wait   the receiver lets its compute stream wait for that event - no host synchronisation, no host staging.
+
+    Sends and receives of a pair match in posting order.  Asynchronous like batch_isend_irecv: a posted send returns as
+    soon as its copy is queued.  `drain()` - after the device is idle - releases the mapped peer buffers and the host
+    messages; call it between passes.  (The bytes never leave the one GPU: what this rehearses is the SCHEDULE of
+    aa.overlapped_e2e on device buffers, event for event, not a link.)"""
+
+    TAG_SIZE, TAG_DESC, TAG_DONE = 11, 12, 13
+
+    def __init__(self, dist, device, n_events=256):
+        import torch
+
+        self.dist, self.dev, self.torch = dist, device, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.side = torch.cuda.Stream(device)
+        self.events = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(n_events)]
+        for e in self.events:
+            e.record(self.side)                      # (an event must have been recorded before its handle is taken)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, [e.ipc_handle() for e in self.events])
+        self.peer_events = {r: [torch.cuda.Event.from_ipc_handle(device, h) for h in hs]
+                            for r, hs in enumerate(gathered) if r != self.rank}
+        self.seq, self.works, self.keep = 0, [], []
+        self.bytes_sent = 0
+
+    def post(self, ops, group=None):
+        import pickle
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        torch, dist = self.torch, self.dist
+        reqs = []
+        for kind, t, peer in ops:                    # receives first: the senders wait for these descriptors
+            if kind != "recv":
+                continue
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("IpcTransport moves contiguous CUDA tensors")
+            desc = pickle.dumps(reduce_tensor(t))
+            size = torch.tensor([len(desc)], dtype=torch.int64)
+            buf = torch.frombuffer(bytearray(desc), dtype=torch.uint8)
+            self.works += [dist.isend(size, peer, tag=self.TAG_SIZE), dist.isend(buf, peer, tag=self.TAG_DESC)]
+            self.keep += [size, buf, t]
+            reqs.append(_IpcRecv(self, peer))
+        for kind, t, peer in ops:
+            if kind != "send":
+                continue
+            size = torch.zeros(1, dtype=torch.int64)
+            dist.recv(size, peer, tag=self.TAG_SIZE)
+            buf = torch.empty(int(size.item()), dtype=torch.uint8)
+            dist.recv(buf, peer, tag=self.TAG_DESC)
+            fn, args = pickle.loads(buf.numpy().tobytes())
+            dst = fn(*args)                          # the receiver's tensor, mapped into this process
+            if dst.numel() != t.numel():
+                raise ValueError(f"send of {t.numel()} elements meets a receive of {dst.numel()}")
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))      # behind whatever produced t
+            slot = self.seq % len(self.events)
+            self.seq += 1
+            with torch.cuda.stream(self.side):
+                dst.view(-1).copy_(t.reshape(-1), non_blocking=True)
+                self.events[slot].record(self.side)
+            note = torch.tensor([slot], dtype=torch.int64)
+            self.works.append(dist.isend(note, peer, tag=self.TAG_DONE))
+            self.keep += [dst, note, t]
+            self.bytes_sent += t.numel() * t.element_size()
+            reqs.append(_IpcSent())
+        return reqs
+
+    def drain(self):
+        """With the device idle: complete the host messages and let go of the peers' buffers."""
+        self.torch.cuda.synchronize(self.dev)
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], []
+
+
+class _IpcRecv:
+    def __init__(self, tr, peer):
+        self.tr, self.peer = tr, peer
+
+    def wait(self):
+        tr = self.tr
+        note = tr.torch.zeros(1, dtype=tr.torch.int64)
+        tr.dist.recv(note, self.peer, tag=tr.TAG_DONE)           # "copy and event are queued"
+        tr.torch.cuda.current_stream(tr.dev).wait_event(tr.peer_events[self.peer][int(note.item())])
+
+
+class _IpcSent:
+    def wait(self):
+        pass
 
 
 def gather_rows(rows, shard, dst=None, out=None):
@@ -148,7 +262,8 @@ def gather_rows(rows, shard, dst=None, out=None):
     return torch.cat([b[:f1 - f0] for b, (f0, f1) in zip(blocks, ranges)], dim=0)
 
 
-def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, out=None, group_in=None, group_out=None):
+def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, out=None, group_in=None, group_out=None,
+                   trace=None, post=None):
     """scatter -> compute -> gather of a whole job with the three legs overlapped, over torch.distributed: every
     rank's frame range is cut into `n_pieces` pieces (shard_piece) and piece k + 1's samples travel while piece k
     is transformed and piece k - 1's rows go back to `src`.
@@ -164,7 +279,13 @@ def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, o
     the "nccl" backend a wait() orders the current stream behind the exchange, and an exchange posted after a
     launch is ordered behind it, so compute k overlaps scatter k + 1 and gather k - 1 on the device.  Every rank
     posts S0, S1, G0, S2, G1, .. in this order (one communicator serialises them in issue order; pass two groups
-    to let scatters and gathers run side by side)."""
+    to let scatters and gathers run side by side).
+
+      trace    optional list: the schedule as it was issued - ("S", k) scatter k posted, ("W", k) piece k's samples
+               waited for, ("C", k) compute k queued (empty pieces included), ("G", k) gather k posted, ("J",) the
+               gathers joined; `overlap_counts(trace)` says how many computes were queued with an exchange in flight
+      post     optional transport: post(ops, group) -> requests with .wait(), ops = [("send" | "recv", tensor, peer)];
+               default: torch.distributed.batch_isend_irecv"""
     import torch
     import torch.distributed as dist
 
@@ -181,11 +302,15 @@ def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, o
         local = torch.empty(shard.local_samples, dtype=torch.float32, device=dev)
         rows = torch.empty((shard.local_frames, cols), dtype=torch.float32, device=dev)
 
-    def post(ops, group):
+    def post_default(ops, group):
         if not ops or shard.world == 1:
             return []
         batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
         return dist.batch_isend_irecv(batch)
+
+    if post is None:
+        post = _TRANSPORT if _TRANSPORT is not None else post_default
+    note = trace.append if trace is not None else (lambda entry: None)
 
     def scatter(k):
         ops = []
@@ -214,19 +339,59 @@ def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, o
         return post(ops, group_out)
 
     pending = {0: scatter(0)}
+    note(("S", 0))
     tail = []
     for k in range(P):
         if k + 1 < P:
             pending[k + 1] = scatter(k + 1)
+            note(("S", k + 1))
         for req in pending.pop(k):
             req.wait()
+        note(("W", k))
         q0, q1 = shard_piece(shard.f0, shard.f1, P, k)
         if q1 > q0:
             execute(local, q0 - shard.f0, q1 - shard.f0, rows)
+        note(("C", k))
         tail += gather(k)
+        note(("G", k))
     for req in tail:
         req.wait()
+    note(("J",))
     return local, rows, (out if root else None)
+
+
+def overlap_counts(trace, n_pieces):
+    """What a trace of overlapped_e2e says about the schedule, by counting (not timing): of the n_pieces computes, how
+    many were queued while the NEXT piece's scatter was already posted and not yet waited for (`scatter_ahead`), and how
+    many while an earlier piece's gather was posted and not yet joined (`gather_behind`) - n_pieces - 1 each when the
+    three legs overlap as designed, 0 each in the serial leg.  Also checks the issue order S0, S1, [W0 C0] G0, S2,
+    [W1 C1] G1, .. and raises ValueError if the trace departs from it."""
+    P = int(n_pieces)
+    want = [("S", 0)]
+    for k in range(P):
+        if k + 1 < P:
+            want.append(("S", k + 1))
+        want += [("W", k), ("C", k), ("G", k)]
+    want.append(("J",))
+    if list(trace) != want:
+        raise ValueError(f"schedule departs from S0 S1 W0 C0 G0 S2 ..: {list(trace)[:12]} ..")
+    posted_s, waited_s, posted_g, joined = set(), set(), set(), False
+    scatter_ahead = gather_behind = 0
+    for entry in trace:
+        kind = entry[0]
+        if kind == "S":
+            posted_s.add(entry[1])
+        elif kind == "W":
+            waited_s.add(entry[1])
+        elif kind == "G":
+            posted_g.add(entry[1])
+        elif kind == "J":
+            joined = True
+        elif kind == "C":
+            k = entry[1]
+            scatter_ahead += 1 if (k + 1) in posted_s and (k + 1) not in waited_s else 0
+            gather_behind += 1 if any(g < k for g in posted_g) and not joined else 0
+    return {"pieces": P, "scatter_ahead": scatter_ahead, "gather_behind": gather_behind}
 
 
 def gather_samples(local, shard, dst=0):

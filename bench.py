@@ -763,13 +763,16 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
         dist.barrier()
         comp.sync()
         ta = time.perf_counter()
+        trace = []
         aa.overlapped_e2e(full, shard, comp.execute_range, comp.cols, n_pieces=E2E_PIECES, src=0, device=out.device,
-                          out=rows_root)
+                          out=rows_root, trace=trace)
         comp.sync()
         tb = time.perf_counter()
         if p:
             over.append(max_over_ranks(tb - ta))
     overlapped = float(np.median(over))
+    # the schedule itself, counted (not timed): computes queued with the next scatter / an earlier gather in flight
+    sched = aa.overlap_counts(trace, E2E_PIECES)
     post_err_overlapped = post_check(rows_root) if rank == 0 else None
     if ctx is not None:
         ctx.update(shard=shard, full=full, out=out, rows_root=rows_root, nf=nf)
@@ -817,6 +820,10 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
             "overlap": {"pieces_per_rank": E2E_PIECES, "total_ms": r4(overlapped * 1e3),
                         "speedup_vs_serial": r4(e2e[3] / overlapped),
                         "post_check_max_err": post_err_overlapped,
+                        # counted, not timed: computes queued with the next piece's scatter / an earlier piece's gather
+                        # posted and not yet waited for (pieces - 1 each when the legs overlap as designed)
+                        "computes_with_scatter_in_flight": sched["scatter_ahead"],
+                        "computes_with_gather_in_flight": sched["gather_behind"],
                         "how": "aa.overlapped_e2e: batch_isend_irecv per piece, waited for where the data is needed"},
         },
         "post_check_max_err": post_err if post_err_overlapped is None else max(post_err, post_err_overlapped),
@@ -837,12 +844,27 @@ def run_multi(args):
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     # AA_BENCH_REHEARSAL=1 (development only): several ranks share the GPUs of a smaller box and
     # rendezvous over gloo, to exercise the N > 1 code path where no N-GPU node is available.
-    rehearsal = os.environ.get("AA_BENCH_REHEARSAL", "0") == "1"
+    # AA_BENCH_REHEARSAL=ipc (r5): the same, but the ranks that share a GPU exchange THROUGH DEVICE MEMORY (torch IPC
+    # handles, interprocess events: aa.IpcTransport) - the schedule of the overlapped leg on device buffers, no host staging.
+    mode = os.environ.get("AA_BENCH_REHEARSAL", "0")
+    rehearsal = mode in ("1", "ipc")
     dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if rehearsal:
+    transport = None
+    if mode == "ipc":
+        import audio_analyzer_rs_amd as aa
+
+        if torch.cuda.device_count() != 1:
+            raise SystemExit("AA_BENCH_REHEARSAL=ipc is the ONE-GPU rehearsal (every rank on device 0)")
+        dist.init_process_group("gloo")
+        comp = HipCompute(N_FFT, HOP, dev)
+        transport = aa.IpcTransport(dist, dev)
+        aa.set_transport(transport.post)
+        hip_sync = comp.sync
+        comp.sync = lambda: (hip_sync(), transport.drain())
+    elif rehearsal:
         dist.init_process_group("gloo")
         comp = RehearsalCompute(N_FFT, HOP, dev)
     else:
@@ -853,7 +875,10 @@ def run_multi(args):
     rc = 0
     result = run_sharded(dist, comp, world, rank, total, args.steps, args.warmup, ctx=ctx)
     if rank == 0:
-        if rehearsal:
+        if mode == "ipc":
+            result["config"]["parallelism"] += (" (REHEARSAL: the ranks share ONE GPU and exchange through its memory - IPC "
+                                                "handles, interprocess events; no link is crossed)")
+        elif rehearsal:
             result["config"]["parallelism"] += " (REHEARSAL: ranks share GPUs, gloo, host-staged exchanges)"
         write_detail(result, world)
         print(json.dumps(result), flush=True)            # the ONE line; nothing below can take it back

@@ -88,7 +88,32 @@ def test_bench_sharded_path_over_gloo(tmp_path, world):
     # the overlapped leg delivered the same rows (its own post-check, piece edges included)
     assert res["e2e"]["overlap"]["pieces_per_rank"] == 8
     assert res["e2e"]["overlap"]["post_check_max_err"] <= res["post_check_tol"]
+    # the overlap itself, by counting instead of by time (host-staged gloo has no transport to hide): every compute but
+    # the last was queued with the next piece's samples on their way, every one but the first with rows still travelling
+    assert res["e2e"]["overlap"]["computes_with_scatter_in_flight"] == 7
+    assert res["e2e"]["overlap"]["computes_with_gather_in_flight"] == 7
     assert res["roofline"]["frames_per_launch"] == frames // world
+
+
+def test_overlap_counts_tell_schedules_apart():
+    """aa.overlap_counts on hand-made traces: the designed schedule, the serial one (rejected: not the issue order), and
+    a schedule that waits for every gather at once (no rows in flight behind a compute)."""
+    sys.path.insert(0, ROOT)
+    import audio_analyzer_rs_amd as aa
+
+    P = 4
+    good = [("S", 0)]
+    for k in range(P):
+        good += ([("S", k + 1)] if k + 1 < P else []) + [("W", k), ("C", k), ("G", k)]
+    good.append(("J",))
+    assert aa.overlap_counts(good, P) == {"pieces": P, "scatter_ahead": P - 1, "gather_behind": P - 1}
+    serial = []
+    for k in range(P):
+        serial += [("S", k), ("W", k), ("C", k), ("G", k)]
+    serial.append(("J",))
+    with pytest.raises(ValueError):
+        aa.overlap_counts(serial, P)
+    assert aa.overlap_counts([("S", 0), ("W", 0), ("C", 0), ("G", 0), ("J",)], 1) == {"pieces": 1, "scatter_ahead": 0, "gather_behind": 0}
 
 
 def test_bench_refuses_mismatched_world(monkeypatch):
