@@ -144,7 +144,7 @@ class IpcTransport:
     messages; call it between passes.  (The bytes never leave the one GPU: what this rehearses is the SCHEDULE of
     aa.overlapped_e2e on device buffers, event for event, not a link.)"""
 
-    TAG_SIZE, TAG_DESC, TAG_DONE = 11, 12, 13
+    TAG_DESC, TAG_HANDLE, TAG_DONE = 11, 12, 13
 
     def __init__(self, dist, device, n_events=256):
         import torch
@@ -160,6 +160,8 @@ class IpcTransport:
         self.peer_events = {r: [torch.cuda.Event.from_ipc_handle(device, h) for h in hs]
                             for r, hs in enumerate(gathered) if r != self.rank}
         self.seq, self.works, self.keep = 0, [], []
+        self.announced = {}                          # (peer, storage address, bytes) -> id: handles this rank has sent
+        self.opened = {}                             # (peer, id) -> the peer's storage as a flat float32 tensor
         self.bytes_sent = 0
 
     def post(self, ops, group=None):
@@ -171,44 +173,66 @@ class IpcTransport:
         for kind, t, peer in ops:                    # receives first: the senders wait for these descriptors
             if kind != "recv":
                 continue
-            if not (t.is_cuda and t.is_contiguous()):
-                raise ValueError("IpcTransport moves contiguous CUDA tensors")
-            desc = pickle.dumps(reduce_tensor(t))
-            size = torch.tensor([len(desc)], dtype=torch.int64)
-            buf = torch.frombuffer(bytearray(desc), dtype=torch.uint8)
-            self.works += [dist.isend(size, peer, tag=self.TAG_SIZE), dist.isend(buf, peer, tag=self.TAG_DESC)]
-            self.keep += [size, buf, t]
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise ValueError("IpcTransport moves contiguous CUDA float32 tensors")
+            st = t.untyped_storage()
+            key = (peer, st.data_ptr(), st.nbytes())
+            first = key not in self.announced
+            if first:
+                self.announced[key] = len(self.announced)
+            handle = b""
+            if first:                                # the whole storage once; later receives into it name it by id
+                flat = torch.empty(0, dtype=torch.float32, device=t.device).set_(st, 0, (st.nbytes() // 4,))
+                handle = pickle.dumps(reduce_tensor(flat))
+            desc = torch.tensor([self.announced[key], t.storage_offset(), t.numel(), len(handle)], dtype=torch.int64)
+            self.works.append(dist.isend(desc, peer, tag=self.TAG_DESC))
+            self.keep += [desc, t]
+            if first:
+                buf = torch.frombuffer(bytearray(handle), dtype=torch.uint8)
+                self.works.append(dist.isend(buf, peer, tag=self.TAG_HANDLE))
+                self.keep.append(buf)
             reqs.append(_IpcRecv(self, peer))
         for kind, t, peer in ops:
             if kind != "send":
                 continue
-            size = torch.zeros(1, dtype=torch.int64)
-            dist.recv(size, peer, tag=self.TAG_SIZE)
-            buf = torch.empty(int(size.item()), dtype=torch.uint8)
-            dist.recv(buf, peer, tag=self.TAG_DESC)
-            fn, args = pickle.loads(buf.numpy().tobytes())
-            dst = fn(*args)                          # the receiver's tensor, mapped into this process
-            if dst.numel() != t.numel():
-                raise ValueError(f"send of {t.numel()} elements meets a receive of {dst.numel()}")
+            desc = torch.zeros(4, dtype=torch.int64)
+            dist.recv(desc, peer, tag=self.TAG_DESC)
+            sid, off, numel, hlen = (int(v) for v in desc.tolist())
+            if hlen:
+                buf = torch.empty(hlen, dtype=torch.uint8)
+                dist.recv(buf, peer, tag=self.TAG_HANDLE)
+                fn, args = pickle.loads(buf.numpy().tobytes())
+                self.opened[(peer, sid)] = fn(*args)                 # the receiver's storage, mapped into this process
+            dst = self.opened[(peer, sid)][off:off + numel]
+            if numel != t.numel():
+                raise ValueError(f"send of {t.numel()} elements meets a receive of {numel}")
             self.side.wait_stream(torch.cuda.current_stream(self.dev))      # behind whatever produced t
             slot = self.seq % len(self.events)
             self.seq += 1
             with torch.cuda.stream(self.side):
-                dst.view(-1).copy_(t.reshape(-1), non_blocking=True)
+                dst.copy_(t.reshape(-1), non_blocking=True)
                 self.events[slot].record(self.side)
             note = torch.tensor([slot], dtype=torch.int64)
             self.works.append(dist.isend(note, peer, tag=self.TAG_DONE))
-            self.keep += [dst, note, t]
+            self.keep += [note, t]
             self.bytes_sent += t.numel() * t.element_size()
             reqs.append(_IpcSent())
         return reqs
 
     def drain(self):
-        """With the device idle: complete the host messages and let go of the peers' buffers."""
+        """With the device idle: complete the host messages and let go of what was held for them (the peers' storages
+        stay mapped: the next pass finds them by id - which is why destinations should be buffers that live across
+        passes: a shared block goes back to its owner's allocator only when every peer has let go of it)."""
         self.torch.cuda.synchronize(self.dev)
         for w in self.works:
             w.wait()
         self.works, self.keep = [], []
+
+    def close(self):
+        """Unmap the peers' storages (before the owners exit) and leave together."""
+        self.drain()
+        self.opened.clear()
+        self.dist.barrier()
 
 
 class _IpcRecv:
@@ -263,7 +287,7 @@ def gather_rows(rows, shard, dst=None, out=None):
 
 
 def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, out=None, group_in=None, group_out=None,
-                   trace=None, post=None):
+                   trace=None, post=None, local=None, rows=None):
     """scatter -> compute -> gather of a whole job with the three legs overlapped, over torch.distributed: every
     rank's frame range is cut into `n_pieces` pieces (shard_piece) and piece k + 1's samples travel while piece k
     is transformed and piece k - 1's rows go back to `src`.
@@ -285,7 +309,9 @@ def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, o
                waited for, ("C", k) compute k queued (empty pieces included), ("G", k) gather k posted, ("J",) the
                gathers joined; `overlap_counts(trace)` says how many computes were queued with an exchange in flight
       post     optional transport: post(ops, group) -> requests with .wait(), ops = [("send" | "recv", tensor, peer)];
-               default: torch.distributed.batch_isend_irecv"""
+               default: torch.distributed.batch_isend_irecv
+      local, rows  off `src`: optional buffers of the rank's sample range / rows to use instead of fresh ones (a
+               transport that maps the destinations into the sender, like IpcTransport, then maps them once)"""
     import torch
     import torch.distributed as dist
 
@@ -299,8 +325,12 @@ def overlapped_e2e(full, shard, execute, cols, n_pieces=8, src=0, device=None, o
         local = full[shard.s0:shard.s1]
         rows = out[shard.f0:shard.f1]
     else:
-        local = torch.empty(shard.local_samples, dtype=torch.float32, device=dev)
-        rows = torch.empty((shard.local_frames, cols), dtype=torch.float32, device=dev)
+        if local is None:
+            local = torch.empty(shard.local_samples, dtype=torch.float32, device=dev)
+        if rows is None:
+            rows = torch.empty((shard.local_frames, cols), dtype=torch.float32, device=dev)
+        if local.numel() != shard.local_samples or tuple(rows.shape) != (shard.local_frames, cols):
+            raise ValueError("local / rows do not have the rank's shapes")
 
     def post_default(ops, group):
         if not ops or shard.world == 1:

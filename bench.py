@@ -764,8 +764,10 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
         comp.sync()
         ta = time.perf_counter()
         trace = []
+        # (off the root the rank's buffers live across the passes: a transport that maps destinations into the sender -
+        # the one-GPU rehearsal's - maps them once)
         aa.overlapped_e2e(full, shard, comp.execute_range, comp.cols, n_pieces=E2E_PIECES, src=0, device=out.device,
-                          out=rows_root, trace=trace)
+                          out=rows_root, trace=trace, local=None if rank == 0 else xd, rows=None if rank == 0 else out)
         comp.sync()
         tb = time.perf_counter()
         if p:
@@ -874,6 +876,8 @@ def run_multi(args):
     ctx = {}
     rc = 0
     result = run_sharded(dist, comp, world, rank, total, args.steps, args.warmup, ctx=ctx)
+    if transport is not None:
+        transport.close()
     if rank == 0:
         if mode == "ipc":
             result["config"]["parallelism"] += (" (REHEARSAL: the ranks share ONE GPU and exchange through its memory - IPC "
