@@ -160,7 +160,7 @@ def cpu_baseline(x, min_seconds=8.0, max_reps=20):
 def load_traffic():
     """HBM bytes per launch of the headline kernel from the committed PMC passes (NOT measured in
     this run): (bytes, source file)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
