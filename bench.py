@@ -257,7 +257,7 @@ def copy_ceiling(aa, torch, dev, timer, n_in, n_out):
     out = {}
     for tag in ("placed", "plain"):
         if tag == "placed":
-            slab, kept_us, typical_us = probe.alloc_rows(rows_needed, candidates=256)
+            slab, kept_us, typical_us = probe.alloc_rows(rows_needed, candidates=128)
             slab = slab.view(-1)
             out["placement_probe_us"] = [r4(kept_us), r4(typical_us)]
         else:
@@ -322,7 +322,7 @@ def other_configs(aa, torch, dev, timer, x, xd, steps, warmup):
             ms_plain, _ = timer.time(lambda: plan.execute_device(xin, 0, nf, out=plain, stream=st), steps, warmup)
             del plain
             t_alloc = time.perf_counter()
-            buf, kept_us, typical_us = plan.alloc_rows(nf, candidates=256)
+            buf, kept_us, typical_us = plan.alloc_rows(nf, candidates=128)
             extra = {"rows": "aa_rows_alloc", "ms_plain_alloc": r4(ms_plain), "alloc_s": r4(time.perf_counter() - t_alloc),
                      "alloc_kept_us": r4(kept_us), "alloc_typical_us": r4(typical_us),
                      "frac_plain_alloc": r4(bytes_per_frame * nf / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS)}
