@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
         initialized = init_flags ? init_flags[blockIdx.y] : 0;
     }
     const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
-    const float VOL_MEMORY = 0.75f, NOTE_RATIO = 1.5f, NOTE_VOL_MAX = 0.15f;
+    const float VOL_MEMORY = 0.75f, NOTE_VOL_MAX = 0.15f;     // (NOTE_RATIO = 1.5: in the exact product below)
     float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
     bool init = initialized != 0;
     auto frame = [&](float mag, float gf) {
@@ -1462,10 +1462,15 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
             const float delta = fabsf(mag - prev);
             vol = vol * VOL_MEMORY + delta * (1.0f - VOL_MEMORY);
             prev = mag;
-            const float above_ratio = mag / fmaxf(fl, 0.01f);
+            // r5: `mag / floor.max(0.01) > NOTE_RATIO` (stft.rs:346, 351) without the division.  The quotient is used for
+            // nothing but this comparison, and for a correctly rounded q = RN(a / b): q > 1.5 <=> a / b > 1.5 + 2^-24 (the
+            // midpoint above 1.5; a tie rounds to the even 1.5) <=> a > b * (1.5 + 2^-24), which a double product of two
+            // floats and a 25-bit constant forms exactly.  Infinities, NaNs, over- and underflowing quotients come out
+            // the same (tests/test_gpu_parity.py::test_exact_ratio_test_is_the_division); four instructions for twelve.
+            const bool above = (double)mag > (double)fmaxf(fl, 0.01f) * 1.500000059604644775390625;
             float vn = vol / fmaxf(mag, 0.05f);
             vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
-            const bool sustained = above_ratio > NOTE_RATIO && vn < NOTE_VOL_MAX;
+            const bool sustained = above && vn < NOTE_VOL_MAX;
             const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn : FLOOR_RELEASE;
             const float moved = fl + alpha * (mag - fl);
             fl = sustained ? fl : moved;

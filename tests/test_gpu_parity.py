@@ -1044,6 +1044,46 @@ def test_tuner_pitches_match_restatement(aa, oracle_mod, torch_mod):
     assert np.allclose(f2.cpu().numpy(), r2[0], rtol=1e-5) and np.allclose(s2.cpu().numpy(), r2[1], rtol=1e-5)
 
 
+def test_exact_ratio_test_is_the_division(aa, oracle_mod, torch_mod):
+    """r5: the tuner floor decides `mag / floor.max(0.01) > 1.5` (stft.rs:346, 351) by an exact double product instead of
+    the f32 quotient.  Adversarial rows: a first frame sets every bin's floor to a random value b over sixty binades, the
+    second frame's magnitudes sit on and a few ulps around RN(1.5 b) (where the rounded quotient flips), plus huge, tiny,
+    infinite and NaN values; with its volatility low the bin freezes iff the test holds, so the effective floor of frame 2
+    shows the decision - every bit against the restatement, which divides."""
+    rng = np.random.default_rng(1234)
+    nb = 1025
+    rows = []
+    for rep in range(40):
+        b = (rng.random(nb).astype(np.float32) + np.float32(1.0)) * np.float32(2.0) ** rng.integers(-30, 30, nb).astype(np.float32)
+        target = (np.float32(1.5) * b).astype(np.float32)
+        steps = rng.integers(-3, 4, nb)
+        m1 = target.copy()
+        for _ in range(3):
+            m1 = np.where(steps > 0, np.nextafter(m1, np.float32(np.inf)), np.where(steps < 0, np.nextafter(m1, np.float32(-np.inf)), m1)).astype(np.float32)
+            steps = steps - np.sign(steps)
+        if rep % 8 == 7:                                     # specials in a few places
+            m1[::97] = np.float32(np.inf)
+            m1[5::97] = np.float32(np.nan)
+            m1[11::97] = np.float32(3.0e38)
+            m1[17::97] = np.float32(1e-40)
+            b[23::97] = np.float32(3.0e38)
+        rows += [b, m1, (m1 * np.float32(0.9)).astype(np.float32)]
+    mags = np.stack(rows).astype(np.float32)
+    gf = np.tile(np.array([1e-12, 1e30, 1e30], np.float32), len(rows) // 3)     # frame 0: floor = b; later: eff = floor
+    # fresh state every three frames: streams of three frames each
+    offs = np.arange(0, len(rows) + 1, 3).astype(np.int64)
+    eff, state = aa.tuner_floor(torch_mod.from_numpy(mags).cuda(), torch_mod.from_numpy(gf).cuda(), offsets=torch_mod.from_numpy(offs).cuda())
+    eff, state = eff.cpu().numpy(), state.cpu().numpy()
+    frozen = 0
+    for s_ in range(len(offs) - 1):
+        a, bnd = int(offs[s_]), int(offs[s_ + 1])
+        ref_eff, ref_state, _ = oracle_mod.tuner_floor(mags[a:bnd], gf[a:bnd])
+        assert np.array_equal(eff[a:bnd].view(np.uint32), ref_eff.view(np.uint32)), s_
+        assert np.array_equal(state[s_].view(np.uint32), ref_state.view(np.uint32)), s_
+        frozen += int((ref_eff[1] == mags[a]).sum())
+    assert 0.2 < frozen / (nb * (len(offs) - 1)) < 0.8          # both outcomes occur, about half and half
+
+
 def test_tuner_noise_floor_bit_exact(aa, oracle_mod, torch_mod):
     """First stage of "next" row f-1: the tuner's per-bin adaptive noise floor
     (stft.rs:326-367) on the tuner geometry — a recurrence, evaluated in the reference's
