@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float *__rest
 // contiguous span of the spectrogram, fetched as coalesced 16-byte pieces into registers - the next block's while the
 // current one is walked - and handed over through LDS, where lane t walks row t at an odd stride (n_bins = n_fft/2 + 1:
 // conflict free).  Every element leaves HBM once.  Spectra wider than 129 bins (the onset geometry) go through LDS in
-// column tiles of 126 bins with the same accumulators (kFluxFlat = false).
+// column tiles of 112 bins with the same accumulators (FLAT = false).
 // offsets (nullable): frame_offsets[n_streams + 1] of concatenated streams; the first frame of a stream takes
 // prev0 + s * n_bins (or zeros) as its previous row.  The stream of a block's first frame is found ONCE per block by a
 // 64-ary search across the lanes, the starts inside the block are scattered into an LDS row (ds_max: of several empty
@@ -433,8 +433,9 @@ __global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict_
 
 // Rest of the onset detector's per-frame logic after the flux (src/analysis/onset.rs:298-371,
 // 531-535; "next" row f-2): per-bin rise-once burst floor, silence gate, energy EMA, FluxTracker,
-// combined trigger, energy_rising, velocity and the frames_since_onset gate (offline semantics:
-// transport calibrated, no metronome tick nearby).  A recurrence over frames: ONE wave walks the
+// combined trigger, energy_rising, velocity and the frames_since_onset gate; r4 / r5: what the decision takes from the
+// MusicalTransport - tick guard, calibration window, calibration timeout - as a per-frame mask, the calibration mode as an
+// argument, calibration_done in the state (onset.rs:361-371, 393-440).  A recurrence over frames: ONE wave walks the
 // frames of a stream in order, lanes = bins (floors in LDS), the burst count is a ballot + popcount
 // and the largest excess a wave max (both order-independent), the scalar recurrences run
 // redundantly in every lane in the reference's operation order -> bit-identical to the CPU
