@@ -1676,7 +1676,11 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
     // stream: 313 -> ~30 ms).  r5: at every stream count - rounds 1-4 went back to one wave per stream from 256 streams
     // on, i.e. 1024 streams were 1024 lone waves walking 440 frames at 0.7 us each (351 us); four of these workgroups
     // fit a CU, so 1024 streams are resident at once with five waves per SIMD to issue from
-    if (n_bins <= 192) {
+    // ... down to streams of ~40 frames on average: the split workgroup spends two extra 32-frame steps per stream
+    // filling and draining its stages, so a batch of very short streams (450 000 frames as 16 384 streams: 0.87 ms
+    // split, 0.67 ms one wave each; 8192 streams: 0.48 against 0.53) goes to the one-wave kernel, whose many
+    // resident waves cover each other's latency (tools/gates_sweep.py)
+    if (n_bins <= 192 && n_frames >= (int64_t)40 * n_streams) {
         const int stride = (n_bins + 1) | 1;
         const size_t lds2 = sizeof(float) * (size_t)(kGateOpsDwords + 2 * kGateT * stride + 4 * kGateT);
         hipLaunchKernelGGL(onset_gates_split_kernel, dim3((unsigned)n_streams), dim3(320), lds2, stream, mags, flux, energy,

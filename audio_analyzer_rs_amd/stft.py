@@ -225,16 +225,26 @@ def downmix(interleaved, channels, stream=None):
     return out
 
 
+_OFFSETS_SEEN = {}          # the batch description checked last: a weak reference to the tensor, its version, the frame count
+
+
 def _offsets_arg(offsets, nf):
-    """Validate a batch description: CUDA int64 [n_streams + 1], 0 .. total frames."""
+    """Validate a batch description: CUDA int64 [n_streams + 1], 0 .. total frames.  The check reads the tensor back (a
+    device synchronisation): it is done once per tensor version, so that a chain of calls over the same streams stays
+    asynchronous."""
     import torch
 
     if not (offsets.is_cuda and offsets.dtype == torch.int64 and offsets.dim() == 1 and offsets.is_contiguous()
             and offsets.numel() >= 2):
         raise _lib.AaError(_lib.AA_ERR_ARG, "offsets must be a contiguous CUDA int64 vector [n_streams + 1]")
-    host = offsets.cpu()
-    if int(host[0]) != 0 or int(host[-1]) != nf or bool((host[1:] < host[:-1]).any()):
-        raise _lib.AaError(_lib.AA_ERR_ARG, "offsets must ascend from 0 to the number of frames")
+    seen = _OFFSETS_SEEN.get("last")
+    if not (seen and seen[0]() is offsets and seen[1:] == (offsets._version, int(nf))):
+        host = offsets.cpu()
+        if int(host[0]) != 0 or int(host[-1]) != nf or bool((host[1:] < host[:-1]).any()):
+            raise _lib.AaError(_lib.AA_ERR_ARG, "offsets must ascend from 0 to the number of frames")
+        import weakref
+
+        _OFFSETS_SEEN["last"] = (weakref.ref(offsets), offsets._version, int(nf))   # (the very tensor object, unchanged)
     return offsets.numel() - 1
 
 

@@ -772,7 +772,7 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
                 for key in got:
                     assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), got[key]), (cut, key)
                 assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), cut
-    # the one-wave form (spectra wider than 192 bins, or >= 256 streams) carries the same inputs: 513 bins
+    # the one-wave form (spectra wider than 192 bins, or streams shorter than 40 frames on average) carries the same inputs: 513 bins
     mags1k = aa.Stft(1024, 256, output="mag")(xd)
     f1k, e1k = aa.onset_flux(mags1k)
     n1k = mags1k.shape[0]
@@ -792,7 +792,8 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
 
 
 def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
-    """The five-wave form of the gates (below 256 streams, <= 192 bins) over bin counts around its wave boundaries and
+    """The five-wave form of the gates (<= 192 bins, streams of 40 frames or more on average; shorter ones here run the
+    one-wave form, and meet the five-wave form in test_onset_gates_kernel_choice_by_stream_length) over bin counts around its wave boundaries and
     frame counts around its 32-frame blocks - synthetic magnitudes with bursts, so that every branch of the floor
     update and detected / fired / tick frames occur - bit for bit against the restatement, in one call and in two
     pieces with the state carried, with a suppress mask."""
@@ -828,6 +829,40 @@ def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
                 for key in got:
                     assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), got[key]), (nb, nf, cut, key)
                 assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), (nb, nf, cut)
+
+
+def test_onset_gates_kernel_choice_by_stream_length(aa, oracle_mod, torch_mod):
+    """The launcher takes the five-wave form when the streams average 40 frames or more and the one-wave form below
+    that, so either kernel meets streams of any length inside a ragged batch: the same ragged lengths once next to a
+    long stream (five-wave form) and once on their own (one-wave form), each stream bit for bit against the restatement
+    run on that stream alone, with tick and calibration masks."""
+    rng = np.random.default_rng(79)
+    short = [1, 2, 31, 32, 33, 5, 0, 39, 17]
+    for nb in (33, 129, 192):
+        for lens in (short + [1000], short):
+            nf = sum(lens)
+            assert (nf >= 40 * len(lens)) == (len(lens) == len(short) + 1)
+            base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
+            bursts = rng.random(nf) < 0.1
+            base[bursts] *= (4.0 + 20.0 * rng.random((int(bursts.sum()), nb))).astype(np.float32)
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            gf = (0.01 + 0.02 * rng.random(nf)).astype(np.float32)
+            mk = ((rng.random(nf) < 0.1) | (2 * (rng.random(nf) < 0.3)) | (4 * (rng.random(nf) < 0.02))).astype(np.uint8)
+            mags, offd = torch_mod.from_numpy(base).cuda(), torch_mod.from_numpy(offs).cuda()
+            flux, energy = aa.onset_flux(mags, offsets=offd)
+            f_cpu, e_cpu = flux.cpu().numpy(), energy.cpu().numpy()
+            for mode in (1, 2):
+                got, gstate = aa.onset_gates(mags, flux, energy, torch_mod.from_numpy(gf).cuda(), offsets=offd,
+                                             suppress=torch_mod.from_numpy(mk).cuda(), calibrated=mode)
+                for i, n_i in enumerate(lens):
+                    a, b = int(offs[i]), int(offs[i + 1])
+                    if n_i == 0:
+                        continue
+                    want, wstate, _ = oracle_mod.onset_gates(base[a:b], f_cpu[a:b], e_cpu[a:b], gf[a:b], suppress=mk[a:b],
+                                                             calibrated=mode)
+                    for key in want:
+                        assert np.array_equal(got[key][a:b].cpu().numpy(), want[key]), (nb, len(lens), i, key, mode)
+                    assert np.array_equal(gstate[i].cpu().numpy().view(np.uint32), wstate.view(np.uint32)), (nb, len(lens), i)
 
 
 def test_tuner_floor_block_sizes(aa, oracle_mod, torch_mod):
