@@ -1118,7 +1118,8 @@ int aa_stft_plan_create(const aa_stft_config *cfg, const float *custom_window_ho
                 aa::wave1024_lds_dwords(p->frames_per_wg, cfg->hop, cfg->output == AA_OUT_MFCC ? 4 : 3) <= 16384)
                 p->mel_mfma = build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps, 8, aa::kMelMfmaRowB, false, &mt,
                                              &p->mel_mfma_sched);
-            if (use_mfma && p->wave2048 && cfg->hop == 512 && p->frames_per_wg == 4 && cfg->output == AA_OUT_LOGMEL)
+            // (r5: also under MFCC at the tuner geometry - the log-mel slab the DCT launch reads comes from this kernel)
+            if (use_mfma && p->wave2048 && cfg->hop == 512 && p->frames_per_wg == 4)
                 p->mel_mfma = build_mel_mfma(w, nb, cfg->n_mels, aa::kMelMfmaSteps2048, 8, aa::kMelMfmaScratchDwords, true, &mt,
                                              &p->mel_mfma_sched);
             if (p->mel_mfma) {
@@ -1229,6 +1230,8 @@ const char *aa_stft_mel_path_name(const aa_stft_plan *p)
     const bool mfcc = p->cfg.output == AA_OUT_MFCC;
     if (p->mel_mfma && (!mfcc || p->mfcc_mfma))
         return mfcc ? "mfma+dct" : "mfma";
+    if (mfcc && p->mel_mfma && p->wave2048)
+        return "mfma+gemm";      // the log-mel rows from the 2048 mel kernel, the DCT-II as a second launch
     if (p->fused_mel)
         return mfcc ? "gather+gemm" : "gather";
     return "gemm";
@@ -1400,7 +1403,10 @@ static int execute_device_impl(aa_stft_plan *p, const float *samples_dev, int64_
     }
     if (p->fused_mel && (reinterpret_cast<uintptr_t>(first_sample) & 15u) == 0) {
         auto mel_stage = [&](int64_t fb, int64_t n, float *dst) -> int {
-            if (p->wave2048)
+            if (p->wave2048 && p->mel_mfma && !chn && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
+                AA_HIP(aa::launch_wave2048(aa::kLogMelM, samples_dev, dst, p->d_w1024_tab, fb, n, p->cfg.hop,
+                                           p->frames_per_wg, p->log_floor, st, p->d_mel_mfma, &p->mel_mfma_sched, chn));
+            else if (p->wave2048)
                 AA_HIP(aa::launch_wave2048(aa::kLogMel, samples_dev, dst,
                                            p->d_w1024_tab, fb, n, p->cfg.hop,
                                            p->frames_per_wg, p->log_floor, st, p->d_mel_par, &p->mel_sched, chn));

@@ -164,6 +164,7 @@ const char *aa_stft_kernel_name(const aa_stft_plan *plan);
  *   "mfma"         inside the wave kernel, the filterbank band-blocked on v_mfma_f32_4x4x1 (stft_wave1024_mel_kernel
  *                  at 8 frames per chunk, stft_wave2048_mel_kernel at hop 512; n_mels % 4 == 0, 16-byte-aligned rows);
  *   "mfma+dct"     MFCC: the same with the DCT-II fused behind it (n_fft 1024, n_mfcc <= 64) - one launch;
+ *   "mfma+gemm"    MFCC at n_fft 2048, hop 512: log-mel slab from "mfma", then the DCT-II as an f32 MFMA GEMM;
  *   "gather"       inside the wave kernel on the VALU, weights rebuilt from the triangle edges (any band count / hop);
  *   "gather+gemm"  MFCC: log-mel slab from "gather", then the DCT-II as an f32 MFMA GEMM;
  *   "gemm"         power slab -> f32 MFMA filterbank GEMM (-> DCT GEMM): the generic FFT kernels, and any call whose

@@ -419,7 +419,9 @@ def test_mel_path_names(aa):
     assert mk(1024, 256, "mfcc", n_mels=128, n_mfcc=40) == "mfma+dct"
     assert mk(1024, 256, "mfcc", n_mels=126, n_mfcc=33) == "gather+gemm"
     assert mk(1024, 256, "mfcc", n_mels=128, n_mfcc=80) == "gather+gemm"
-    assert mk(2048, 512, "mfcc", n_mels=128, n_mfcc=40) == "gather+gemm"
+    assert mk(2048, 512, "mfcc", n_mels=128, n_mfcc=40) == "mfma+gemm"        # r5: the slab from the 2048 mel kernel
+    assert mk(2048, 512, "mfcc", n_mels=126, n_mfcc=40) == "gather+gemm"
+    assert mk(2048, 256, "mfcc", n_mels=128, n_mfcc=40) == "gather+gemm"
     assert mk(4096, 1024, "logmel", n_mels=128) == "gemm" and mk(512, 128, "mfcc", n_mels=40, n_mfcc=13) == "gemm"
 
 
