@@ -670,8 +670,8 @@ constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
 // that a single live stream (the reference's shape: onset.rs runs one) no longer walks its frames in one wave at 0.7 us
 // each.  The per-bin floor recurrence (onset.rs:311-332) is independent per bin and feeds the frame only through the
 // burst count and the largest excess ratio; the scalar recurrences (energy EMA :345-350, FluxTracker :66-83, frame gate
-// :531-535) need only those two numbers.  Five waves, three roles, a block of kGateT frames apart each:
-//   A (3 waves) one lane per bin (<= 192 bins): the floor recurrence of block b, the bin's kGateT magnitudes in registers
+// :531-535) need only those two numbers.  Five waves, three roles, a block of T frames apart each:
+//   A (3 waves) one lane per bin (<= 192 bins): the floor recurrence of block b, the bin's T magnitudes in registers
 //               (the next block's prefetched from global memory), the ratio of every (frame, bin) into LDS
 //   R (1 wave)  block b - 1: lanes = (frame, half of the bins) walk their column of ratios: count of ratios above
 //               BIN_BURST_RATIO and their maximum (order-free, so bit-identical to the sequential loop); 32 reads in flight
@@ -687,9 +687,25 @@ constexpr int kMaxNotes = 8, kMaxHarmonics = 14;
 // three with a SIMD to themselves run A.  One workgroup barrier per block.  Every f32 operation of a bin / of the chains
 // is the reference's, in its order (fp contract off): the outputs are bit-identical to onset_gates_kernel and to the C
 // restatement.
-constexpr int kGateT = 32;
-constexpr int kGateOpsDwords = kGateT * 2 * 4 + kGateT * 2 * 2 + 8;   // operand rows, result rows, role table
-__global__ __launch_bounds__(320) void onset_gates_split_kernel(
+// r5: T = frames per block.  32 for a few long streams (the lone waves' prefetch depth: 194 registers, two waves per SIMD,
+// i.e. ONE workgroup per CU); 16 for batches: half the registers and half the LDS, several workgroups per CU, and a
+// stream's pipeline fills and drains in two steps of 16 frames instead of 32.
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)     // a wave-uniform value into scalar registers
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+#ifndef AA_GATES_T16_WAVES
+#define AA_GATES_T16_WAVES 5
+#endif
+#ifndef AA_GATES_T32_WAVES
+#define AA_GATES_T32_WAVES 1
+#endif
+constexpr int gate_ops_dwords(int T) { return T * 2 * 4 + T * 2 * 2 + 8; }   // operand rows, result rows, role table
+template <int T>
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(T == 16 ? AA_GATES_T16_WAVES : AA_GATES_T32_WAVES)))
+void onset_gates_split_kernel(
     const float *__restrict__ mags, const float *__restrict__ flux, const float *__restrict__ energy,
     const float *__restrict__ global_floor, float *__restrict__ state, int initialized, int64_t n_frames,
     int n_bins, float *__restrict__ out_flux, float *__restrict__ out_ema,
@@ -702,8 +718,10 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (offsets) {
-        const int64_t f0 = offsets[blockIdx.x];
-        n_frames = offsets[blockIdx.x + 1] - f0;
+        // (made scalar by hand: the two offsets arrive through vector loads, and every pointer advanced by them would
+        // count as per-lane - each row load with a 64-bit address pair of its own)
+        const int64_t f0 = uniform_i64(offsets[blockIdx.x]);
+        n_frames = uniform_i64(offsets[blockIdx.x + 1]) - f0;
         mags += f0 * n_bins;
         flux += f0;
         energy += f0;
@@ -724,16 +742,16 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     // rows of the ratio image: n_bins columns + a spare one the lanes without a bin write to (no per-frame lane
     // masks), an odd stride (the column walk of the R wave is bank-conflict free)
     const int stride = (n_bins + 1) | 1;
-    float *ops = gate_lds;                           // [kGateT][2][4]: (x, a_rise, a_decay, clamp) of the EMA / of the threshold
-    float *res = ops + kGateT * 2 * 4;               // [kGateT][2][2]: (state behind the frame, x > state in front of it)
-    int *roles = reinterpret_cast<int *>(res + kGateT * 2 * 2);             // [8]
-    float *ratio = gate_lds + kGateOpsDwords;        // [2][kGateT][stride]
-    int *cnts = reinterpret_cast<int *>(ratio + 2 * kGateT * stride);      // [2][kGateT]
-    float *maxs = reinterpret_cast<float *>(cnts + 2 * kGateT);            // [2][kGateT]
+    float *ops = gate_lds;                           // [T][2][4]: (x, a_rise, a_decay, clamp) of the EMA / of the threshold
+    float *res = ops + T * 2 * 4;               // [T][2][2]: (state behind the frame, x > state in front of it)
+    int *roles = reinterpret_cast<int *>(res + T * 2 * 2);             // [8]
+    float *ratio = gate_lds + gate_ops_dwords(T);        // [2][T][stride]
+    int *cnts = reinterpret_cast<int *>(ratio + 2 * T * stride);      // [2][T]
+    float *maxs = reinterpret_cast<float *>(cnts + 2 * T);            // [2][T]
     const float ENERGY_EMA_RISE = 0.84f, ENERGY_EMA_DECAY = 0.95f;
     const float BIN_BURST_RATIO = 2.5f, FLOOR_OVERCOMPENSATE = 1.3f, FLOOR_RISE = 0.1f, FLOOR_DECAY = 0.04f;
     const float multiplier = 1.5f, rise_memory = 0.84f, decay_memory = 0.89f;
-    const int64_t n_blocks = (n_frames + kGateT - 1) / kGateT;
+    const int64_t n_blocks = (n_frames + T - 1) / T;
 
     // ---- roles by SIMD (HW_ID bits 5:4): 0..2 = A for bins 64 role .. 64 role + 63, 3 = R, 4 = B ----
     if (lane == 0)
@@ -769,28 +787,44 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     const bool valid = role < 3 && bin < n_bins;
     const int col = valid ? bin : n_bins;            // (the spare column)
     float fl = valid ? state[bin] : 1.0f;
-    float cur[kGateT], nxt[kGateT];
+    float cur[T], nxt[T];
     float cur_gf = 0.0f, nxt_gf = 0.0f;              // lane i: global_floor of frame i of the block (read by readlane)
-    auto fetch = [&](int64_t b, float (&dst)[kGateT], float &gfv) {
-        const int64_t t0 = b * kGateT;
-        if (t0 + kGateT <= n_frames) {               // (a full block: no per-frame bounds)
-            const float *m = mags + t0 * n_bins + (valid ? bin : 0);
+    auto fetch = [&](int64_t b, float (&dst)[T], float &gfv) {
+        const int64_t t0 = b * T;
+        if (t0 + T <= n_frames) {               // (a full block: no per-frame bounds)
+            // a scalar row pointer + ONE 32-bit lane offset: as per-lane 64-bit addresses the T loads held 2 T registers and
+            // took two vector instructions each to form
+            const char *row = reinterpret_cast<const char *>(mags + t0 * n_bins);
+            const unsigned voff = valid ? 4u * (unsigned)bin : 0u;      // (a BYTE offset: the form the scalar-base load takes)
 #pragma unroll
-            for (int i = 0; i < kGateT; ++i)
-                dst[i] = m[(int64_t)i * n_bins];
+            for (int i = 0; i < T; ++i) {
+                unsigned vo = voff;
+                asm volatile("" : "+v"(vo));     // (opaque per row: or base + offset is formed once, as a per-lane pointer)
+                dst[i] = *reinterpret_cast<const float *>(row + vo);
+                row += 4 * n_bins;
+            }
         } else {
+            // the stream's last block: the rows that exist (wave-uniform count), the others read the last one again
+            const int nrow = (int)(n_frames - t0);
+            const char *row = reinterpret_cast<const char *>(mags + t0 * n_bins);
+            const unsigned voff = valid ? 4u * (unsigned)bin : 0u;
 #pragma unroll
-            for (int i = 0; i < kGateT; ++i)
-                dst[i] = (valid && t0 + i < n_frames) ? mags[(t0 + i) * n_bins + bin] : 0.0f;
+            for (int i = 0; i < T; ++i) {
+                unsigned vo = voff;
+                asm volatile("" : "+v"(vo));
+                dst[i] = *reinterpret_cast<const float *>(row + vo);
+                if (i + 1 < nrow)
+                    row += 4 * n_bins;
+            }
         }
-        gfv = (lane < kGateT && t0 + lane < n_frames) ? global_floor[t0 + lane] : 0.0f;
+        gfv = (lane < T && t0 + lane < n_frames) ? global_floor[t0 + lane] : 0.0f;
     };
     // B: the per-frame inputs of a block, fetched a step ahead as well
     float b_flux = 0.0f, b_energy = 0.0f, n_flux = 0.0f, n_energy = 0.0f;
     int b_sup = 0, n_sup = 0;
     auto fetch_b = [&](int64_t b, float &vf, float &ve, int &vs) {
-        const int64_t t = b * kGateT + lane;
-        const bool in = lane < kGateT && t < n_frames;
+        const int64_t t = b * T + lane;
+        const bool in = lane < T && t < n_frames;
         vf = in ? flux[t] : 0.0f;
         ve = in ? energy[t] : 0.0f;
         vs = (in && suppress) ? (int)suppress[t] : (calibrated == 2 ? 2 : 0);
@@ -807,13 +841,6 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
     }
     if (calibrated != 2)
         cal_done = calibrated == 1;
-    if (role < 3 && n_blocks > 0) {
-        fetch(0, cur, cur_gf);
-        if (!initialized)                            // onset.rs:304-309: the floors start at the first frame's magnitudes
-            fl = fmaxf(cur[0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), 0)));
-    }
-    if (role == 4 && n_blocks > 0)
-        fetch_b(0, b_flux, b_energy, b_sup);
 
     // one frame of one bin (onset.rs:311-332), branch-free: the three candidate floors, two selects
     auto bin_step = [&](float mag, float gf) {
@@ -826,52 +853,60 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
         return r;
     };
 
-    for (int64_t step = 0; step < n_blocks + 2; ++step) {
-        if (role < 3) {
+    // r5: a loop per role (the waves meet at one barrier per step all the same): with the roles as branches of ONE loop the
+    // registers every role carries from step to step - A's two blocks of magnitudes above all - were live in all of them
+    if (role < 3) {
+        fetch(0, cur, cur_gf);
+        if (!initialized)                            // onset.rs:304-309: the floors start at the first frame's magnitudes
+            fl = fmaxf(cur[0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), 0)));
+        for (int64_t step = 0; step < n_blocks + 2; ++step) {
             // ---- per-bin floor recurrence of block `step` ----
             if (step < n_blocks) {
                 if (step + 1 < n_blocks)
                     fetch(step + 1, nxt, nxt_gf);    // in flight while this block is walked
-                const int64_t t0 = step * kGateT;
-                const int nfb = (int)((n_frames - t0) < kGateT ? (n_frames - t0) : kGateT);
-                float *rb = ratio + (step & 1) * kGateT * stride + col;
-                if (nfb == kGateT) {
+                const int64_t t0 = step * T;
+                const int nfb = (int)((n_frames - t0) < T ? (n_frames - t0) : T);
+                float *rb = ratio + (step & 1) * T * stride + col;
+                if (nfb == T) {
 #pragma unroll
-                    for (int i = 0; i < kGateT; ++i)
+                    for (int i = 0; i < T; ++i)
                         rb[i * stride] = bin_step(cur[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), i)));
                 } else {
-                    for (int i = 0; i < nfb; ++i) {
-                        float mag = 0.0f;
 #pragma unroll
-                        for (int j = 0; j < kGateT; ++j)
-                            mag = j == i ? cur[j] : mag;
-                        rb[i * stride] = bin_step(mag, __shfl(cur_gf, i));
-                    }
+                    for (int i = 0; i < T; ++i)          // (the stream's last block: a wave-uniform branch per frame)
+                        if (i < nfb)
+                            rb[i * stride] = bin_step(cur[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), i)));
                 }
 #pragma unroll
-                for (int i = 0; i < kGateT; ++i)
+                for (int i = 0; i < T; ++i)
                     cur[i] = nxt[i];
                 cur_gf = nxt_gf;
             }
-        } else if (role == 3) {
+            __syncthreads();
+        }
+        if (valid)
+            state[bin] = fl;
+    } else if (role == 3) {
+        for (int64_t step = 0; step < n_blocks + 2; ++step) {
             // ---- burst count and largest excess of every frame of block `step - 1` ----
             if (step >= 1 && step <= n_blocks) {
                 const int pb = (int)((step - 1) & 1);
-                const int i = lane & 31, half = lane >> 5;
-                const int nbh = (n_bins + 1) >> 1;
-                const int k0 = half ? nbh : 0, k1 = half ? n_bins : nbh;
-                const float *colp = ratio + pb * kGateT * stride + i * stride;
+                constexpr int PARTS = 64 / T;            // lanes = (frame, part of the bins)
+                const int i = lane & (T - 1), part = lane / T;
+                const int nbh = (n_bins + PARTS - 1) / PARTS;
+                const int k0 = part * nbh < n_bins ? part * nbh : n_bins, k1 = k0 + nbh < n_bins ? k0 + nbh : n_bins;
+                const float *colp = ratio + pb * T * stride + i * stride;
                 int count = 0;
                 float mx = 0.0f;
                 int k = k0;
                 // thirty-two reads in flight: a lone wave sees the whole LDS round trip on every wait
-                for (; k + 32 <= k1; k += 32) {
-                    float r[32];
+                for (; k + T <= k1; k += T) {
+                    float r[T];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j)
+                    for (int j = 0; j < T; ++j)
                         r[j] = colp[k + j];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
+                    for (int j = 0; j < T; ++j) {
                         count += r[j] > BIN_BURST_RATIO ? 1 : 0;
                         mx = r[j] > mx ? r[j] : mx;
                     }
@@ -892,23 +927,30 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                     count += r > BIN_BURST_RATIO ? 1 : 0;
                     mx = r > mx ? r : mx;
                 }
-                count += __shfl_xor(count, 32);
-                const float other = __shfl_xor(mx, 32);
-                mx = other > mx ? other : mx;
-                if (half == 0) {
-                    cnts[pb * kGateT + i] = count;
-                    maxs[pb * kGateT + i] = mx;
+#pragma unroll
+                for (int off = 32; off >= T; off >>= 1) {
+                    count += __shfl_xor(count, off);
+                    const float other = __shfl_xor(mx, off);
+                    mx = other > mx ? other : mx;
+                }
+                if (part == 0) {
+                    cnts[pb * T + i] = count;
+                    maxs[pb * T + i] = mx;
                 }
             }
-        } else {
+            __syncthreads();
+        }
+    } else {
+        fetch_b(0, b_flux, b_energy, b_sup);
+        for (int64_t step = 0; step < n_blocks + 2; ++step) {
             // ---- the frame's gates and the recurrences of block `step - 2` ----
             if (step >= 2) {
-                const int64_t b = step - 2, t0 = b * kGateT;
+                const int64_t b = step - 2, t0 = b * T;
                 const int pb = (int)(b & 1);
-                const int nfb = (int)((n_frames - t0) < kGateT ? (n_frames - t0) : kGateT);
+                const int nfb = (int)((n_frames - t0) < T ? (n_frames - t0) : T);
                 const bool mine = lane < nfb;
-                const int count = mine ? cnts[pb * kGateT + lane] : 0;
-                const float mx = mine ? maxs[pb * kGateT + lane] : 0.0f;
+                const int count = mine ? cnts[pb * T + lane] : 0;
+                const float mx = mine ? maxs[pb * T + lane] : 0.0f;
                 float v_flux = b_flux;
                 const float v_energy = b_energy;
                 const int v_sup = b_sup;
@@ -921,7 +963,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 const bool bo = mx > 3.0f && count >= 3;
                 float vel = fmaxf(v_flux, mx * 5.0f) / 50.0f;
                 vel = vel < 0.0f ? 0.0f : (vel > 1.0f ? 1.0f : vel);
-                if (lane < kGateT) {
+                if (lane < T) {
                     v4f *row = reinterpret_cast<v4f *>(ops + 8 * lane);
                     row[0] = v4f{v_energy, v_energy * (1.0f - ENERGY_EMA_RISE), v_energy * (1.0f - ENERGY_EMA_DECAY), -INFINITY};
                     row[1] = v4f{v_flux, v_flux * (1.0f - rise_memory), v_flux * (1.0f - decay_memory), 0.9f};
@@ -940,24 +982,25 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                     chain_s = chain_s < o.w ? o.w : chain_s;          // (the threshold's 0.9 floor; -inf for the EMA)
                     *reinterpret_cast<v2f *>(res_b + 16 * i) = v2f{chain_s, up ? 1.0f : 0.0f};
                 };
-                if (nfb == kGateT) {
-                    // operand rows eight frames at a time, the next eight in flight while these are stepped (the reads
+                if (nfb == T) {
+                    // operand rows T / 4 frames at a time, the next ones in flight while these are stepped (the reads
                     // stand in front of the result writes in program order: the compiler need not reorder LDS accesses
                     // it cannot tell apart, and the wave does not sit out an LDS round trip per frame)
-                    v4f o[2][8];
+                    constexpr int G = T / 4;
+                    v4f o[2][G];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < G; ++j)
                         o[0][j] = *reinterpret_cast<const v4f *>(ops_b + 32 * j);
 #pragma unroll
-                    for (int k = 0; k < kGateT / 8; ++k) {
-                        if (k + 1 < kGateT / 8) {
+                    for (int k = 0; k < T / G; ++k) {
+                        if (k + 1 < T / G) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                o[(k + 1) & 1][j] = *reinterpret_cast<const v4f *>(ops_b + 32 * (8 * (k + 1) + j));
+                            for (int j = 0; j < G; ++j)
+                                o[(k + 1) & 1][j] = *reinterpret_cast<const v4f *>(ops_b + 32 * (G * (k + 1) + j));
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            chain(o[k & 1][j], 8 * k + j);
+                        for (int j = 0; j < G; ++j)
+                            chain(o[k & 1][j], G * k + j);
                     }
                 } else {
                     for (int i = 0; i < nfb; ++i)
@@ -965,7 +1008,7 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 }
                 __builtin_amdgcn_wave_barrier();
                 // back to lane = frame: the frame's flags from the two states behind it
-                const int fr = lane < kGateT ? lane : 0;
+                const int fr = lane < T ? lane : 0;
                 const v2f r_ema = *reinterpret_cast<const v2f *>(res + 4 * fr), r_thr = *reinterpret_cast<const v2f *>(res + 4 * fr + 2);
                 const float ema_i = r_ema.x, thr_i = r_thr.x;
                 const bool is_onset = r_thr.y != 0.0f;
@@ -1024,12 +1067,8 @@ __global__ __launch_bounds__(320) void onset_gates_split_kernel(
                 b_energy = n_energy;
                 b_sup = n_sup;
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (valid)
-        state[bin] = fl;
-    if (role == 4) {
         if (lane == 0)
             state[n_bins] = chain_s;
         if (lane == 32)
@@ -1661,6 +1700,12 @@ hipError_t launch_flux_div3_check(uint32_t first, uint64_t n, unsigned long long
     return hipGetLastError();
 }
 
+// blocks of 16 frames from here on: up to 3 x 256 streams the T = 32 workgroups are all resident (measured: 512 streams
+// 0.108 ms against 0.115, 1024 streams 0.144 against 0.100)
+#ifndef AA_GATES_T16_FROM
+#define AA_GATES_T16_FROM 768
+#endif
+
 hipError_t launch_onset_gates(const float *mags, const float *flux, const float *energy,
                               const float *global_floor, float *state, int initialized, int64_t n_frames,
                               int n_bins, float *out_flux, float *out_ema, float *out_excess,
@@ -1674,18 +1719,23 @@ hipError_t launch_onset_gates(const float *mags, const float *flux, const float 
         return hipErrorInvalidValue;
     // the onset geometry: the recurrences taken apart, one workgroup of five waves per stream (a single ten-minute
     // stream: 313 -> ~30 ms).  r5: at every stream count - rounds 1-4 went back to one wave per stream from 256 streams
-    // on, i.e. 1024 streams were 1024 lone waves walking 440 frames at 0.7 us each (351 us); four of these workgroups
-    // fit a CU, so 1024 streams are resident at once with five waves per SIMD to issue from
-    // ... down to streams of ~40 frames on average: the split workgroup spends two extra 32-frame steps per stream
-    // filling and draining its stages, so a batch of very short streams (450 000 frames as 16 384 streams: 0.87 ms
-    // split, 0.67 ms one wave each; 8192 streams: 0.48 against 0.53) goes to the one-wave kernel, whose many
-    // resident waves cover each other's latency (tools/gates_sweep.py)
-    if (n_bins <= 192 && n_frames >= (int64_t)40 * n_streams) {
+    // on, i.e. 1024 streams were 1024 lone waves walking 440 frames at 0.7 us each (351 us).
+    // r5, second pass (tools/gates_sweep.py, 449 997 frames of 129 bins): a loop per role and scalar-base row loads took
+    // the kernel from 194 to 118 registers (T = 32: three workgroups per CU, one before) and to 78 in blocks of 16 frames
+    // (four per CU) - 1024 streams 186 -> 100 us, 8192 streams 0.48 -> 0.14 ms, and ahead of the one-wave kernel down to
+    // streams of three frames (131 072 streams: 0.89 against 1.58 ms), which is left with the wide spectra
+    if (n_bins <= 192) {
         const int stride = (n_bins + 1) | 1;
-        const size_t lds2 = sizeof(float) * (size_t)(kGateOpsDwords + 2 * kGateT * stride + 4 * kGateT);
-        hipLaunchKernelGGL(onset_gates_split_kernel, dim3((unsigned)n_streams), dim3(320), lds2, stream, mags, flux, energy,
-                           global_floor, state, initialized, n_frames, n_bins, out_flux, out_ema, out_excess, out_count,
-                           out_flags, out_velocity, offsets, init_flags, suppress, calibrated);
+#define AA_GATES_SPLIT(T)                                                                                             \
+    hipLaunchKernelGGL(onset_gates_split_kernel<T>, dim3((unsigned)n_streams), dim3(320),                              \
+                       sizeof(float) * (size_t)(gate_ops_dwords(T) + 2 * T * stride + 4 * T), stream, mags, flux,      \
+                       energy, global_floor, state, initialized, n_frames, n_bins, out_flux, out_ema, out_excess,      \
+                       out_count, out_flags, out_velocity, offsets, init_flags, suppress, calibrated)
+        if (n_streams > AA_GATES_T16_FROM)
+            AA_GATES_SPLIT(16);
+        else
+            AA_GATES_SPLIT(32);
+#undef AA_GATES_SPLIT
         return hipGetLastError();
     }
     int fpb = 64 * kGatePrefetchRegs / n_bins;       // frames per prefetched block, one lane per frame

@@ -774,7 +774,7 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
                 for key in got:
                     assert torch_mod.equal(torch_mod.cat([o1[key], o2[key]]), got[key]), (cut, key)
                 assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), cut
-    # the one-wave form (spectra wider than 192 bins, or streams shorter than 40 frames on average) carries the same inputs: 513 bins
+    # the one-wave form (spectra wider than 192 bins) carries the same inputs: 513 bins
     mags1k = aa.Stft(1024, 256, output="mag")(xd)
     f1k, e1k = aa.onset_flux(mags1k)
     n1k = mags1k.shape[0]
@@ -794,8 +794,7 @@ def test_onset_gates_bit_exact(aa, oracle_mod, torch_mod, n, hop):
 
 
 def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
-    """The five-wave form of the gates (<= 192 bins, streams of 40 frames or more on average; shorter ones here run the
-    one-wave form, and meet the five-wave form in test_onset_gates_kernel_choice_by_stream_length) over bin counts around its wave boundaries and
+    """The five-wave form of the gates (<= 192 bins) over bin counts around its wave boundaries and
     frame counts around its 32-frame blocks - synthetic magnitudes with bursts, so that every branch of the floor
     update and detected / fired / tick frames occur - bit for bit against the restatement, in one call and in two
     pieces with the state carried, with a suppress mask."""
@@ -833,17 +832,19 @@ def test_onset_gates_split_kernel_sizes(aa, oracle_mod, torch_mod):
                 assert torch_mod.equal(s2.view(torch_mod.int32), gstate.view(torch_mod.int32)), (nb, nf, cut)
 
 
-def test_onset_gates_kernel_choice_by_stream_length(aa, oracle_mod, torch_mod):
-    """The launcher takes the five-wave form when the streams average 40 frames or more and the one-wave form below
-    that, so either kernel meets streams of any length inside a ragged batch: the same ragged lengths once next to a
-    long stream (five-wave form) and once on their own (one-wave form), each stream bit for bit against the restatement
-    run on that stream alone, with tick and calibration masks."""
+def test_onset_gates_ragged_batches_both_block_lengths(aa, oracle_mod, torch_mod):
+    """The five-wave form walks blocks of 32 frames up to 768 streams and blocks of 16 frames beyond (r5: four
+    workgroups per CU): ragged batches for both - lengths around the block boundaries, empty streams, one long stream -
+    each stream bit for bit against the restatement run on that stream alone, with tick and calibration masks."""
     rng = np.random.default_rng(79)
     short = [1, 2, 31, 32, 33, 5, 0, 39, 17]
+    # more than 768 streams: the five-wave form in blocks of 16 frames (r5), lengths around its block boundaries
+    many = [int(v) for v in rng.integers(0, 40, 800)] + [15, 16, 17, 31, 32, 33, 47, 48, 49, 0, 1, 200]
+    many += [777]
+    assert len(many) > 768
     for nb in (33, 129, 192):
-        for lens in (short + [1000], short):
+        for lens in (short + [1000], short, many):
             nf = sum(lens)
-            assert (nf >= 40 * len(lens)) == (len(lens) == len(short) + 1)
             base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
             bursts = rng.random(nf) < 0.1
             base[bursts] *= (4.0 + 20.0 * rng.random((int(bursts.sum()), nb))).astype(np.float32)

@@ -14,7 +14,7 @@ def timed(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for ns in (256, 512, 1024, 2048, 4096, 8192, 16384, 65536):
+for ns in [int(v) for v in os.environ.get("AA_SWEEP", "1,16,64,128,256,512,1024,2048,4096,8192,16384").split(",")]:
     offs = torch.tensor(np.linspace(0, nf, ns + 1).astype(np.int64), device="cuda")
     flux, energy = aa.onset_flux(mags, offsets=offs)
     print(os.path.basename(sys.argv[1]), ns, "streams:", round(timed(lambda: aa.onset_gates(mags, flux, energy, gf, offsets=offs)), 4), "ms", flush=True)
