@@ -1096,7 +1096,10 @@ void onset_gates_split_kernel(
 //     notes one per lane.
 // 17.7 KB of LDS per frame in flight at the tuner's 1025 bins (nine waves per CU).
 constexpr int kPitH = kMaxHarmonics - 1;            // harmonics n = 2 .. 14
-constexpr int kPitGroup = 64;                       // strong peaks per scoring pass
+#ifndef AA_PIT_GROUP
+#define AA_PIT_GROUP 16
+#endif
+constexpr int kPitGroup = AA_PIT_GROUP;             // strong peaks per scoring pass
 __device__ __forceinline__ float pit_wave_max(float v)
 {
 #pragma unroll
@@ -1117,14 +1120,16 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     const int half_size = n_bins;
     float *m = pit_lds;
     uint32_t *mask32 = reinterpret_cast<uint32_t *>(m + nbp);              // [2 nw + 2] peak bits, 64 bins per pair of words
-    int *peak_bin = reinterpret_cast<int *>(mask32 + 2 * nw + 2);           // strong peaks, bin order
-    float *peak_nf = reinterpret_cast<float *>(peak_bin + max_peaks);
-    float *frac = peak_nf + max_peaks, *score = frac + max_peaks;
-    uint32_t *hw = reinterpret_cast<uint32_t *>(score + max_peaks);         // [64][13] harmonic results of a group
+    // strong peaks, bin order: the bin in 15 bits, bit 15 = "fundamental below 15 x its floor" (all the score needs of the
+    // floor, stft.rs:546) - r5: 10 bytes per possible peak instead of 16, the kept notes on the dead magnitude row; the
+    // kernel's time follows the waves a CU holds (9 at 17.7 KB: 191 us, 11: 175, 15: 120 with a narrower peak range)
+    uint16_t *peak_bin = reinterpret_cast<uint16_t *>(mask32 + 2 * nw + 2);
+    float *frac = reinterpret_cast<float *>(peak_bin + ((max_peaks + 1) & ~1)), *score = frac + max_peaks;
+    uint32_t *hw = reinterpret_cast<uint32_t *>(score + max_peaks);         // [kPitGroup][13] harmonic results of a group
     float *hm = reinterpret_cast<float *>(hw + kPitGroup * kPitH);
-    // later stages on dead areas (every stage ends in a workgroup barrier)
-    int *cand = peak_bin;
-    float *kfrac = peak_nf, *kscore = max_peaks <= kPitGroup * kPitH ? reinterpret_cast<float *>(hw) : hm + kPitGroup * kPitH;
+    // later stages on dead areas (every stage ends in a workgroup barrier): the magnitudes are not read behind the scores
+    uint16_t *cand = peak_bin;
+    float *kfrac = 2 * max_peaks <= nbp ? m : hm + kPitGroup * kPitH, *kscore = kfrac + max_peaks;
     float *sfrac = frac, *sscore = score;
     const unsigned long long lt = (1ull << lane) - 1ull;
     constexpr int kIt = 17;
@@ -1216,8 +1221,7 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
             const unsigned long long smask = __ballot(strong);
             if (strong) {
                 const int pos = n_strong + __popcll(smask & lt);
-                peak_bin[pos] = k;
-                peak_nf[pos] = nfk;
+                peak_bin[pos] = (uint16_t)(k | (mk < 15.0f * nfk ? 0x8000 : 0));
             }
             n_strong += __popcll(smask);
         };
@@ -1244,10 +1248,11 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
             const int gcount = n_strong - g0 < kPitGroup ? n_strong - g0 : kPitGroup;
             const bool mine = lane < gcount;
             int k = 2;
-            float fund_mag = 0.0f, nfk = 0.0f, frac_bin = 0.0f;
+            float fund_mag = 0.0f, frac_bin = 0.0f;
+            bool below15 = false;
             if (mine) {
-                k = peak_bin[g0 + lane];
-                nfk = peak_nf[g0 + lane];
+                k = peak_bin[g0 + lane] & 0x7fff;
+                below15 = (peak_bin[g0 + lane] & 0x8000) != 0;
                 fund_mag = m[k];
                 frac_bin = (float)k;
                 if (k >= 1 && k + 1 < half_size) {
@@ -1283,7 +1288,7 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
                         // the end of what the walk can have taken before: the peak's own bin (n = 2), or the previous window
                         int pe;
                         if (n == 2) {
-                            pe = peak_bin[g0 + sl];
+                            pe = peak_bin[g0 + sl] & 0x7fff;
                         } else {
                             pe = (int)ceilf(fb * (float)(n - 1) + 1.0f);
                             if (pe > half_size - 1)
@@ -1338,7 +1343,7 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
                 if (!all_noconf)
                     acc = walk_slow(k, frac_bin, fund_mag, longest_run, total_harms);
                 float sc = 0.0f;
-                if (!(longest_run < 3 && fund_mag < 15.0f * nfk)) {
+                if (!(longest_run < 3 && below15)) {
                     const float log_score = log2f(0.5f + acc);
                     const float struct_mult =
                         (1.0f + (float)longest_run + (float)total_harms / 2.0f) / (1.0f + (float)kMaxHarmonics);
@@ -1359,7 +1364,7 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
                 const bool c = p < n_strong && score[p] >= cutoff;
                 const unsigned long long mask = __ballot(c);
                 if (c)
-                    cand[n_cand + __popcll(mask & lt)] = p;
+                    cand[n_cand + __popcll(mask & lt)] = (uint16_t)p;
                 n_cand += __popcll(mask);
             }
             __syncthreads();
@@ -1777,9 +1782,12 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
     if (max_peaks < 1)
         max_peaks = 1;
     const int nbp = (n_bins + 3) & ~3, nw = (n_bins + 63) >> 6;
-    size_t words = (size_t)nbp + (size_t)(2 * nw + 2) + 4 * (size_t)max_peaks + 2 * (size_t)(kPitGroup * kPitH);
-    if (max_peaks > kPitGroup * kPitH)
-        words += (size_t)max_peaks;                  // the kept scores do not fit the dead harmonic area
+    if (n_bins > 0x7fff)
+        return hipErrorInvalidValue;                 // (a peak's bin travels in 15 bits)
+    size_t words = (size_t)nbp + (size_t)(2 * nw + 2) + (size_t)((max_peaks + 1) / 2) + 2 * (size_t)max_peaks +
+                   2 * (size_t)(kPitGroup * kPitH);
+    if (2 * max_peaks > nbp)
+        words += 2 * (size_t)max_peaks;              // the kept notes do not fit the dead magnitude row
     const size_t lds = sizeof(float) * words;
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
