@@ -1467,6 +1467,200 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
     }
 }
 
+// One frame of one bin of the tuner's noise floor (stft.rs:326-367): the state (floor, previous magnitude, volatility)
+// moves on, the effective floor min(floor, 2.5 x global floor) is returned.  The stream's very first frame sets the
+// state instead (tuner_floor_first); the callers peel it off their loops - as a flag tested per frame it cost a branch
+// and an exec mask in every one of them.
+__device__ __forceinline__ float tuner_floor_first(float &fl, float &prev, float mag, float gf)
+{
+#pragma clang fp contract(off)
+    fl = fmaxf(mag, gf * 5.0f);
+    prev = mag;
+    return fminf(fl, gf * 2.5f);
+}
+__device__ __forceinline__ float tuner_floor_step(float &fl, float &prev, float &vol, float mag, float gf)
+{
+#pragma clang fp contract(off)
+    const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
+    const float VOL_MEMORY = 0.75f, NOTE_VOL_MAX = 0.15f;     // (NOTE_RATIO = 1.5: in the exact test below)
+    const float delta = fabsf(mag - prev);
+    vol = vol * VOL_MEMORY + delta * (1.0f - VOL_MEMORY);
+    prev = mag;
+    // r5: `mag / floor.max(0.01) > NOTE_RATIO` (stft.rs:346, 351) without the division.  The quotient is used for
+    // nothing but this comparison, and for a correctly rounded q = RN(a / b): q > 1.5 <=> a / b > 1.5 + 2^-24 (the
+    // midpoint above 1.5; a tie rounds to the even 1.5) <=> a - 1.5 b > b 2^-24.  With b in [2^e, 2^(e+1)) both a
+    // (near 1.5 b) and 1.5 b are multiples of 2^(e-24), so wherever the difference is small enough to matter
+    // (< 2^e) ONE fused multiply-add returns it exactly, and beyond that its rounded value has the right sign
+    // and size; b 2^-24 is an exact scaling (b >= 0.01).  Infinities, NaNs, over- and underflowing quotients come
+    // out the same (tests/test_gpu_parity.py::test_exact_ratio_test_is_the_division); three f32 instructions for
+    // twelve (first version of the round: a double product, four instructions at half rate).
+    const float den = fmaxf(fl, 0.01f);
+    const bool above = __builtin_fmaf(den, -1.5f, mag) > den * 5.9604644775390625e-08f;
+    float vn = vol / fmaxf(mag, 0.05f);
+    vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
+    const bool sustained = above && vn < NOTE_VOL_MAX;
+    const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn : FLOOR_RELEASE;
+    const float moved = fl + alpha * (mag - fl);
+    fl = sustained ? fl : moved;
+    return fminf(fl, gf * 2.5f);
+}
+
+// r5: the batch form.  tuner_floor_kernel below gives every wave 64 bins of one stream: 256-byte pieces of rows that are
+// 4100 bytes apart - three cache lines for two, the partial ones filled before they are written (343 + 254 MB moved for
+// 2 x 231 MB) - and with trivial arithmetic in place of the recurrence the launch takes the same 155-165 us: it is bound
+// by that access pattern.  Here ONE workgroup owns a stream: the rows of kRowsT consecutive frames are one contiguous
+// span of the spectrogram, fetched as aligned 16-byte pieces (the next span's while this one is walked), handed over
+// through LDS, walked in place one lane per bin, and written back as aligned 16-byte pieces of the effective-floor
+// rows.  A row of the tuner geometry has 1025 bins and a workgroup 1024 lanes: wave 0 walks the last bin as a second
+// pass.  Same arithmetic, same order: bit-identical to the kernel below and to the C restatement.
+// a workgroup barrier that orders the LDS accesses only: __syncthreads() also waits for every global load and store in
+// flight - the next span's pieces, fetched to arrive DURING the walk, and the row stores of the span before
+__device__ __forceinline__ void rows_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+constexpr int kRowsT = 8, kRowsP = 3;               // frames per span; 16-byte pieces per lane (>= (8 * 1025 + 6) / 4 / 1024)
+__global__ __launch_bounds__(1024) void tuner_floor_rows_kernel(
+    const float *__restrict__ mags, const float *__restrict__ global_floor, float *__restrict__ state,
+    float *__restrict__ eff, int n_bins, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t f0 = uniform_i64(offsets[blockIdx.x]);
+    const int64_t n_frames = uniform_i64(offsets[blockIdx.x + 1]) - f0;
+    if (n_frames <= 0)
+        return;
+    mags += f0 * n_bins;
+    eff += f0 * n_bins;
+    global_floor += f0;
+    state += (int64_t)blockIdx.x * 3 * n_bins;
+    const bool seen = (init_flags ? init_flags[blockIdx.x] : 0) != 0;
+    const bool valid = tid < n_bins;
+    const int k = valid ? tid : n_bins - 1;
+    const bool extra = n_bins == nthr + 1 && wave == 0;          // (wave-uniform) the row's last bin rides on wave 0
+    const int kx = n_bins - 1;
+    float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
+    float xfl = 0.0f, xprev = 0.0f, xvol = 0.0f;
+    if (extra) {
+        xfl = state[kx];
+        xprev = state[n_bins + kx];
+        xvol = state[2 * n_bins + kx];
+    }
+    const int n_pieces = (kRowsT * n_bins + 6 + 3) >> 2;         // covers a span at any 16-byte phase
+    const int64_t n_steps = (n_frames + kRowsT - 1) / kRowsT;
+    v4f regs[kRowsP];
+    float gfv = 0.0f;
+    // span of step s: floats [s0, s0 + n) of the stream's rows; piece q = floats 4 q - lead .. + 3 of it, fetched from
+    // the 16-byte boundary below s0 (pieces that straddle an end of the span float by float: nothing outside is touched)
+    auto span_of = [&](int64_t s, const float *base, int64_t &s0, int &n, int &lead) {
+        s0 = s * kRowsT * (int64_t)n_bins;
+        const int64_t left = n_frames - s * kRowsT;
+        n = (int)(left < kRowsT ? left : kRowsT) * n_bins;
+        lead = (int)((reinterpret_cast<uintptr_t>(base + s0) & 15u) >> 2);
+    };
+    auto fetch = [&](int64_t s) {
+        int64_t s0;
+        int n, lead;
+        span_of(s, mags, s0, n, lead);
+        const float *base = mags + s0 - lead;                    // 16-byte aligned
+#pragma unroll
+        for (int u = 0; u < kRowsP; ++u) {
+            const int q = tid + nthr * u, j = 4 * q - lead;
+            v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (j >= 0 && j + 4 <= n) {
+                v = *reinterpret_cast<const v4f *>(base + 4 * q);
+            } else if (j + 4 > 0 && j < n) {
+                v.x = (j + 0 >= 0 && j + 0 < n) ? base[4 * q + 0] : 0.0f;
+                v.y = (j + 1 >= 0 && j + 1 < n) ? base[4 * q + 1] : 0.0f;
+                v.z = (j + 2 >= 0 && j + 2 < n) ? base[4 * q + 2] : 0.0f;
+                v.w = (j + 3 >= 0 && j + 3 < n) ? base[4 * q + 3] : 0.0f;
+            }
+            regs[u] = v;
+        }
+        const int64_t t = s * kRowsT + lane;                     // lane i < kRowsT: the global floor of frame i of the span
+        gfv = (lane < kRowsT && t < n_frames) ? global_floor[t] : 0.0f;
+    };
+    fetch(0);
+    for (int64_t s = 0; s < n_steps; ++s) {
+        int64_t s0;
+        int n, lead;
+        span_of(s, mags, s0, n, lead);
+#pragma unroll
+        for (int u = 0; u < kRowsP; ++u) {
+            const int q = tid + nthr * u;
+            if (q < n_pieces)
+                reinterpret_cast<v4f *>(rows_lds)[q] = regs[u];
+        }
+        const float gf_here = gfv;
+        rows_barrier();                                          // the span is in LDS
+        if (s + 1 < n_steps)
+            fetch(s + 1);                                        // in flight while this span is walked
+        const int nfb = n / n_bins;
+        // All reads of a column stand in front of its writes (in place the compiler cannot move one over the other).  No
+        // lane is masked: the lanes past the row (always in the wave of its last bin) and the 64 lanes of wave 0 on the
+        // extra bin read the same values in lockstep and write the same results to the same slots.
+        const bool fresh = s == 0 && !seen;                      // (uniform) the span opens with the stream's first frame
+        auto walk = [&](float *col, float &a, float &b, float &c) {
+            float m[kRowsT];
+#pragma unroll
+            for (int i = 0; i < kRowsT; ++i)
+                m[i] = col[i * n_bins];                          // (rows past the span's last one: stale LDS, not used)
+            auto gf_of = [&](int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gf_here), i)); };
+            if (fresh)
+                col[0] = tuner_floor_first(a, b, m[0], gf_of(0));
+            else
+                col[0] = tuner_floor_step(a, b, c, m[0], gf_of(0));
+            if (nfb == kRowsT) {
+#pragma unroll
+                for (int i = 1; i < kRowsT; ++i)
+                    col[i * n_bins] = tuner_floor_step(a, b, c, m[i], gf_of(i));
+            } else {
+#pragma unroll
+                for (int i = 1; i < kRowsT; ++i)
+                    if (i < nfb)                                 // (wave-uniform: a stream's last span)
+                        col[i * n_bins] = tuner_floor_step(a, b, c, m[i], gf_of(i));
+            }
+        };
+        walk(rows_lds + lead + k, fl, prev, vol);
+        if (extra)
+            walk(rows_lds + lead + kx, xfl, xprev, xvol);
+        rows_barrier();                                          // the span holds the effective floors
+        {
+            const int lead_e = (int)((reinterpret_cast<uintptr_t>(eff + s0) & 15u) >> 2);
+            float *base = eff + s0 - lead_e;                     // 16-byte aligned
+#pragma unroll
+            for (int u = 0; u < kRowsP; ++u) {
+                const int q = tid + nthr * u, j = 4 * q - lead_e;
+                const float *src = rows_lds + lead + j;          // float j of the span
+                if (j >= 0 && j + 4 <= n) {
+                    // (both buffers at one 16-byte phase - the usual case: one ds_read_b128; four dword reads at a
+                    // stride of four banks are served eight lanes at a time)
+                    const v4f v = lead == lead_e ? reinterpret_cast<const v4f *>(rows_lds)[q] : v4f{src[0], src[1], src[2], src[3]};
+                    *reinterpret_cast<v4f *>(base + 4 * q) = v;
+                } else if (j + 4 > 0 && j < n) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (j + c >= 0 && j + c < n)
+                            base[4 * q + c] = src[c];
+                }
+            }
+        }
+        rows_barrier();                                          // every lane has read its pieces: the next span may land
+    }
+    if (valid) {
+        state[k] = fl;
+        state[n_bins + k] = prev;
+        state[2 * n_bins + k] = vol;
+    }
+    if (extra && lane == 0) {
+        state[kx] = xfl;
+        state[n_bins + kx] = xprev;
+        state[2 * n_bins + kx] = xvol;
+    }
+}
+
 // Tuner front end (src/audio_io/stft.rs:326-367), first stage of "next" row f-1: the variance-
 // aware per-bin noise floor.  It is a recurrence over frames, independent per bin: one lane per
 // bin walks the frames in order with exactly the reference's operation order (contraction off,
@@ -1486,61 +1680,66 @@ __global__ __launch_bounds__(64) void tuner_floor_kernel(const float *__restrict
     const int k = valid ? (int)(blockIdx.x * 64 + threadIdx.x) : n_bins - 1;
     if (offsets) {
         // batch: blockIdx.y walks stream s = frames [offsets[s], offsets[s+1]) of the concatenated arrays
-        const int64_t f0 = offsets[blockIdx.y];
-        n_frames = offsets[blockIdx.y + 1] - f0;
+        const int64_t f0 = uniform_i64(offsets[blockIdx.y]);        // (scalar: the row pointers below stay scalar)
+        n_frames = uniform_i64(offsets[blockIdx.y + 1]) - f0;
         mags += f0 * n_bins;
         eff += f0 * n_bins;
         global_floor += f0;
         state += (int64_t)blockIdx.y * 3 * n_bins;
         initialized = init_flags ? init_flags[blockIdx.y] : 0;
     }
-    const float FLOOR_BASE_ALPHA = 0.04f, FLOOR_FAST_ALPHA = 0.35f, FLOOR_RELEASE = 0.02f;
-    const float VOL_MEMORY = 0.75f, NOTE_VOL_MAX = 0.15f;     // (NOTE_RATIO = 1.5: in the exact product below)
     float fl = state[k], prev = state[n_bins + k], vol = state[2 * n_bins + k];
-    bool init = initialized != 0;
-    auto frame = [&](float mag, float gf) {
-        if (!init) {
-            fl = fmaxf(mag, gf * 5.0f);
-            prev = mag;
-            init = true;
-        } else {
-            const float delta = fabsf(mag - prev);
-            vol = vol * VOL_MEMORY + delta * (1.0f - VOL_MEMORY);
-            prev = mag;
-            // r5: `mag / floor.max(0.01) > NOTE_RATIO` (stft.rs:346, 351) without the division.  The quotient is used for
-            // nothing but this comparison, and for a correctly rounded q = RN(a / b): q > 1.5 <=> a / b > 1.5 + 2^-24 (the
-            // midpoint above 1.5; a tie rounds to the even 1.5) <=> a > b * (1.5 + 2^-24), which a double product of two
-            // floats and a 25-bit constant forms exactly.  Infinities, NaNs, over- and underflowing quotients come out
-            // the same (tests/test_gpu_parity.py::test_exact_ratio_test_is_the_division); four instructions for twelve.
-            const bool above = (double)mag > (double)fmaxf(fl, 0.01f) * 1.500000059604644775390625;
-            float vn = vol / fmaxf(mag, 0.05f);
-            vn = vn < 0.0f ? 0.0f : (vn > 1.0f ? 1.0f : vn);
-            const bool sustained = above && vn < NOTE_VOL_MAX;
-            const float alpha = mag > fl ? FLOOR_BASE_ALPHA + (FLOOR_FAST_ALPHA - FLOOR_BASE_ALPHA) * vn : FLOOR_RELEASE;
-            const float moved = fl + alpha * (mag - fl);
-            fl = sustained ? fl : moved;
-        }
-        return fminf(fl, gf * 2.5f);
-    };
+    auto frame = [&](float mag, float gf) { return tuner_floor_step(fl, prev, vol, mag, gf); };
     // r4: blocks of kFloorT frames - the bin's magnitudes and the frames' global floors of a block are fetched together
-    // (one memory round trip per block instead of one per frame: a ten-minute stream 26.7 -> ~6 ms), then walked
+    // (one memory round trip per block instead of one per frame: a ten-minute stream 26.7 -> 7.6 ms), then walked.
+    // r5: the NEXT block is fetched before this one is walked (a lone wave sat out the round trip once per block:
+    // 7.6 -> 6.8 ms for the one stream); rows are addressed as a scalar pointer + one byte offset per lane (per-lane
+    // 64-bit pointers cost a vector add per load and per store); the lanes past the row walk its last bin and store ITS
+    // value again - no branch; the stream's first frame is peeled off.  This kernel serves up to 255 streams: at 256
+    // streams its launch (153-163 us by box) moves 343 + 254 MB for 2 x 231 MB algorithmic (rows of 4100 B in 256-byte
+    // pieces per wave: three cache lines for two, partial lines filled before they are written) and takes the same
+    // time with the recurrence replaced by an addition - tuner_floor_rows_kernel above takes the batches.
     constexpr int kFloorT = 32;
     const int lane = threadIdx.x;
-    int64_t t = 0;
-    for (; t + kFloorT <= n_frames; t += kFloorT) {
-        float m[kFloorT];
-        const float *mp = mags + t * n_bins + k;
-#pragma unroll
-        for (int i = 0; i < kFloorT; ++i)
-            m[i] = mp[(int64_t)i * n_bins];
-        const float gfv = global_floor[t + (lane & (kFloorT - 1))];      // lane i: frame i of the block
-        float *ep = eff + t * n_bins + k;
+    const unsigned voff = 4u * (unsigned)k;
+    float cur[kFloorT], nxt[kFloorT];
+    float cur_gf = 0.0f, nxt_gf = 0.0f;
+    auto fetch = [&](int64_t t0, float (&dst)[kFloorT], float &gfv) {
+        const char *row = reinterpret_cast<const char *>(mags + t0 * n_bins);
 #pragma unroll
         for (int i = 0; i < kFloorT; ++i) {
-            const float e = frame(m[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gfv), i)));
-            if (valid)
-                ep[(int64_t)i * n_bins] = e;
+            unsigned vo = voff;
+            asm volatile("" : "+v"(vo));         // (opaque per row: or base + offset becomes a per-lane pointer again)
+            dst[i] = *reinterpret_cast<const float *>(row + vo);
+            row += 4 * n_bins;
         }
+        gfv = global_floor[t0 + (lane & (kFloorT - 1))];                 // lane i: frame i of the block
+    };
+    int64_t t = 0;
+    if (!initialized && n_frames > 0) {                          // the stream's first frame sets the state
+        const float e = tuner_floor_first(fl, prev, mags[k], global_floor[0]);
+        if (valid)
+            eff[k] = e;
+        t = 1;
+    }
+    if (t + kFloorT <= n_frames)
+        fetch(t, cur, cur_gf);
+    for (; t + kFloorT <= n_frames; t += kFloorT) {
+        if (t + 2 * kFloorT <= n_frames)
+            fetch(t + kFloorT, nxt, nxt_gf);
+        char *erow = reinterpret_cast<char *>(eff + t * n_bins);
+#pragma unroll
+        for (int i = 0; i < kFloorT; ++i) {
+            const float e = frame(cur[i], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur_gf), i)));
+            unsigned vo = voff;
+            asm volatile("" : "+v"(vo));
+            *reinterpret_cast<float *>(erow + vo) = e;
+            erow += 4 * n_bins;
+        }
+#pragma unroll
+        for (int i = 0; i < kFloorT; ++i)
+            cur[i] = nxt[i];
+        cur_gf = nxt_gf;
     }
     for (; t < n_frames; ++t) {
         const float e = frame(mags[t * n_bins + k], global_floor[t]);
@@ -1803,12 +2002,26 @@ hipError_t launch_tuner_pitches(const float *mags, const float *eff_floor, int64
     return hipGetLastError();
 }
 
+#ifndef AA_FLOOR_ROWS_FROM
+#define AA_FLOOR_ROWS_FROM 256
+#endif
 hipError_t launch_tuner_floor(const float *mags, const float *global_floor, float *state,
                               int initialized, float *eff, int64_t n_frames, int n_bins,
                               hipStream_t stream, const int64_t *offsets, const int32_t *init_flags, int n_streams)
 {
     if (n_frames <= 0 || n_streams <= 0)
         return hipSuccess;
+    // batches of streams whose rows fit a workgroup (one lane per bin, the tuner's 1025th bin as a second pass of wave 0):
+    // rows through LDS in contiguous spans (tuner_floor_rows_kernel)
+    const int rows_threads = n_bins == 1025 ? 1024 : ((n_bins + 63) / 64) * 64;
+    if (offsets && n_streams >= AA_FLOOR_ROWS_FROM && n_bins >= 64 && rows_threads <= 1024) {
+        const size_t lds = sizeof(float) * (size_t)(4 * ((kRowsT * n_bins + 6 + 3) >> 2));
+        if ((kRowsT * n_bins + 6 + 3) / 4 <= kRowsP * rows_threads && lds <= 64 * 1024) {
+            hipLaunchKernelGGL(tuner_floor_rows_kernel, dim3((unsigned)n_streams), dim3((unsigned)rows_threads), lds, stream,
+                               mags, global_floor, state, eff, n_bins, offsets, init_flags);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(tuner_floor_kernel, dim3((unsigned)((n_bins + 63) / 64), (unsigned)n_streams), dim3(64), 0,
                        stream, mags, global_floor, state, initialized, eff, n_frames, n_bins, offsets, init_flags);
     return hipGetLastError();

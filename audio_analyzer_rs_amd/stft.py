@@ -346,23 +346,31 @@ def onset_gates(mags, flux, energy, global_floor, state=None, stream=None, offse
     return out, state
 
 
-def tuner_floor(mags, global_floor, state=None, stream=None, offsets=None):
+def tuner_floor(mags, global_floor, state=None, stream=None, offsets=None, initialized=None):
     """Per-bin adaptive noise floor of the tuner (src/audio_io/stft.rs:326-367) for a CUDA float32
     magnitude spectrogram [frames, bins].  global_floor: CUDA float32 [frames]
     (= 10^(noise_floor_db/20) * bins / 2 per frame).  state: None for a fresh stream, or the
-    [3, bins] tensor returned by a previous call.  Returns (effective_floor, state)."""
+    [3, bins] tensor returned by a previous call.  offsets (CUDA int64 [n_streams + 1]): independent streams laid
+    end to end; state is then [n_streams, 3, bins] and initialized (CUDA int32 [n_streams], default: all ones when
+    a state is passed) says which streams carry one - a stream that has had no frame yet stays fresh.
+    Returns (effective_floor, state)."""
     import torch
 
     lib = _lib.load()
     nf, nb = mags.shape
-    initialized = state is not None
+    per_stream, initialized = initialized, state is not None
     ns = _offsets_arg(offsets, nf) if offsets is not None else None
     if state is None:
         state = torch.zeros((3, nb) if ns is None else (ns, 3, nb), dtype=torch.float32, device=mags.device)
     eff = torch.empty_like(mags)
     st = stream if stream is not None else torch.cuda.current_stream(mags.device).cuda_stream
     if nf and ns is not None:
-        init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
+        if per_stream is None:
+            init = torch.full((ns,), 1 if initialized else 0, dtype=torch.int32, device=mags.device)
+        else:
+            init = per_stream.to(device=mags.device, dtype=torch.int32).contiguous()
+            if init.numel() != ns:
+                raise ValueError("initialized must hold one int32 per stream")
         _lib.check(lib.aa_tuner_floor_batch_device(mags.data_ptr(), offsets.data_ptr(), ns, nf, nb,
                                                    global_floor.data_ptr(), state.data_ptr(), init.data_ptr(),
                                                    eff.data_ptr(), st))

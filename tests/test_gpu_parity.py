@@ -891,6 +891,56 @@ def test_tuner_floor_block_sizes(aa, oracle_mod, torch_mod):
                 assert torch_mod.equal(s2.view(torch_mod.int32), state.view(torch_mod.int32)), (nb, nf, cut)
 
 
+def test_tuner_floor_rows_kernel_batches(aa, oracle_mod, torch_mod):
+    """From 256 streams on the tuner floor takes the rows through LDS in contiguous spans of eight frames, one workgroup
+    per stream (r5; the tuner's 1025th bin as a second pass of wave 0): ragged batches - stream lengths around the span
+    length, empty streams, rows that start at every 16-byte phase - for bin counts with and without the extra bin, in
+    one call and in two with the state carried per stream; bit for bit against the restatement stream by stream."""
+    rng = np.random.default_rng(81)
+    for nb in (1025, 513, 1024, 200, 64):
+        lens = [int(v) for v in rng.integers(0, 30, 260)] + [0, 1, 7, 8, 9, 15, 16, 17, 100]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nf = int(offs[-1])
+        base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
+        loud = rng.random(nf) < 0.15
+        base[loud] *= (3.0 + 30.0 * rng.random((int(loud.sum()), nb))).astype(np.float32)
+        gf = (0.01 + 0.03 * rng.random(nf)).astype(np.float32)
+        # a leading pad float so that the first row sits at another 16-byte phase than the allocation
+        pad = torch_mod.empty(nf * nb + 3, device="cuda")
+        for phase in (0, 1, 3):
+            mags = pad[phase:phase + nf * nb].view(nf, nb)
+            mags.copy_(torch_mod.from_numpy(base))
+            offd, gfd = torch_mod.from_numpy(offs).cuda(), torch_mod.from_numpy(gf).cuda()
+            eff, state = aa.tuner_floor(mags, gfd, offsets=offd)
+            for i, n_i in enumerate(lens):
+                a, b = int(offs[i]), int(offs[i + 1])
+                if n_i == 0:
+                    assert not bool(state[i].any()), (nb, i)          # untouched
+                    continue
+                ref_eff, ref_state, _ = oracle_mod.tuner_floor(base[a:b], gf[a:b])
+                assert np.array_equal(eff[a:b].cpu().numpy().view(np.uint32), ref_eff.view(np.uint32)), (nb, phase, i)
+                assert np.array_equal(state[i].cpu().numpy().view(np.uint32), ref_state.view(np.uint32)), (nb, phase, i)
+        # two calls: every stream cut somewhere (also at 0 and at its end), the state and "seen a frame" carried
+        cuts = [int(rng.integers(0, n_i + 1)) for n_i in lens]
+        first = np.concatenate([np.arange(offs[i], offs[i] + cuts[i]) for i in range(len(lens))]).astype(np.int64)
+        second = np.concatenate([np.arange(offs[i] + cuts[i], offs[i + 1]) for i in range(len(lens))]).astype(np.int64)
+        o1 = np.concatenate([[0], np.cumsum(cuts)]).astype(np.int64)
+        o2 = np.concatenate([[0], np.cumsum([n_i - c for n_i, c in zip(lens, cuts)])]).astype(np.int64)
+        m_all, g_all = torch_mod.from_numpy(base).cuda(), torch_mod.from_numpy(gf).cuda()
+        i1, i2 = torch_mod.from_numpy(first).cuda(), torch_mod.from_numpy(second).cuda()
+        e1, s1 = aa.tuner_floor(m_all[i1].contiguous(), g_all[i1].contiguous(), offsets=torch_mod.from_numpy(o1).cuda())
+        seen = torch_mod.tensor([1 if c > 0 else 0 for c in cuts], dtype=torch_mod.int32, device="cuda")
+        e2, s2 = aa.tuner_floor(m_all[i2].contiguous(), g_all[i2].contiguous(), offsets=torch_mod.from_numpy(o2).cuda(),
+                                state=s1, initialized=seen)
+        whole, wstate = aa.tuner_floor(m_all, g_all, offsets=torch_mod.from_numpy(offs).cuda())
+        joined = torch_mod.empty_like(whole)
+        joined[i1] = e1
+        joined[i2] = e2
+        assert torch_mod.equal(joined.view(torch_mod.int32), whole.view(torch_mod.int32)), nb
+        live = torch_mod.tensor([n_i > 0 for n_i in lens], device="cuda")
+        assert torch_mod.equal(s2[live].view(torch_mod.int32), wstate[live].view(torch_mod.int32)), nb
+
+
 def test_batched_streams_equal_per_stream_calls(aa, torch_mod):
     """The detectors are recurrences over one stream's frames; the batch entry points walk many
     streams (laid end to end, frame_offsets) in parallel - one wave / one lane per bin per stream.
