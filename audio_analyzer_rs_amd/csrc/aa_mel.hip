@@ -1519,7 +1519,10 @@ __device__ __forceinline__ void rows_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-constexpr int kRowsT = 8, kRowsP = 3;               // frames per span; 16-byte pieces per lane (>= (8 * 1025 + 6) / 4 / 1024)
+// kRowsT frames per span, kRowsP 16-byte pieces per lane (>= (kRowsT * 1025 + 9) / 4 / 1024).  Eight frames while a
+// CU holds one workgroup (fewer steps: 137 us at 256 streams against 174 with four); four frames from two workgroups
+// per CU on - the other workgroup's walk fills the time this one moves its rows (121 us against 140 at 512 streams).
+template <int kRowsT, int kRowsP>
 __global__ __launch_bounds__(1024) void tuner_floor_rows_kernel(
     const float *__restrict__ mags, const float *__restrict__ global_floor, float *__restrict__ state,
     float *__restrict__ eff, int n_bins, const int64_t *__restrict__ offsets, const int32_t *__restrict__ init_flags)
@@ -2015,10 +2018,15 @@ hipError_t launch_tuner_floor(const float *mags, const float *global_floor, floa
     // rows through LDS in contiguous spans (tuner_floor_rows_kernel)
     const int rows_threads = n_bins == 1025 ? 1024 : ((n_bins + 63) / 64) * 64;
     if (offsets && n_streams >= AA_FLOOR_ROWS_FROM && n_bins >= 64 && rows_threads <= 1024) {
-        const size_t lds = sizeof(float) * (size_t)(4 * ((kRowsT * n_bins + 6 + 3) >> 2));
-        if ((kRowsT * n_bins + 6 + 3) / 4 <= kRowsP * rows_threads && lds <= 64 * 1024) {
-            hipLaunchKernelGGL(tuner_floor_rows_kernel, dim3((unsigned)n_streams), dim3((unsigned)rows_threads), lds, stream,
-                               mags, global_floor, state, eff, n_bins, offsets, init_flags);
+        const int T = n_streams >= 2 * AA_FLOOR_ROWS_FROM ? 4 : 8, P = T == 4 ? 2 : 3;
+        const size_t lds = sizeof(float) * (size_t)(4 * ((T * n_bins + 6 + 3) >> 2));
+        if ((T * n_bins + 6 + 3) / 4 <= P * rows_threads && lds <= 64 * 1024) {
+            if (T == 4)
+                hipLaunchKernelGGL((tuner_floor_rows_kernel<4, 2>), dim3((unsigned)n_streams), dim3((unsigned)rows_threads),
+                                   lds, stream, mags, global_floor, state, eff, n_bins, offsets, init_flags);
+            else
+                hipLaunchKernelGGL((tuner_floor_rows_kernel<8, 3>), dim3((unsigned)n_streams), dim3((unsigned)rows_threads),
+                                   lds, stream, mags, global_floor, state, eff, n_bins, offsets, init_flags);
             return hipGetLastError();
         }
     }

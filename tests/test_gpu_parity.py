@@ -893,12 +893,13 @@ def test_tuner_floor_block_sizes(aa, oracle_mod, torch_mod):
 
 def test_tuner_floor_rows_kernel_batches(aa, oracle_mod, torch_mod):
     """From 256 streams on the tuner floor takes the rows through LDS in contiguous spans of eight frames, one workgroup
-    per stream (r5; the tuner's 1025th bin as a second pass of wave 0): ragged batches - stream lengths around the span
-    length, empty streams, rows that start at every 16-byte phase - for bin counts with and without the extra bin, in
+    per stream (r5; the tuner's 1025th bin as a second pass of wave 0; spans of four frames from 512 streams on): ragged
+    batches - stream lengths around the span lengths, empty streams, rows that start at every 16-byte phase - for bin counts with and without the extra bin, in
     one call and in two with the state carried per stream; bit for bit against the restatement stream by stream."""
     rng = np.random.default_rng(81)
-    for nb in (1025, 513, 1024, 200, 64):
-        lens = [int(v) for v in rng.integers(0, 30, 260)] + [0, 1, 7, 8, 9, 15, 16, 17, 100]
+    for nb, count in ((1025, 260), (1025, 520), (513, 260), (1024, 520), (200, 260), (64, 520)):
+        # (from 512 streams on the spans are four frames long: the lengths straddle both span lengths)
+        lens = [int(v) for v in rng.integers(0, 30, count)] + [0, 1, 3, 4, 5, 7, 8, 9, 15, 16, 17, 100]
         offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         nf = int(offs[-1])
         base = (0.02 + 0.05 * rng.random((nf, nb))).astype(np.float32)
