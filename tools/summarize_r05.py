@@ -39,8 +39,9 @@ for tag in ("kt_head", "kt_all"):
         f.write("# rocprofv3 --kernel-trace --stats of tools/profile_r05.sh (%s)\n" % tag)
         f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent\n")
         for r in rows:
-            f.write("%s,%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
-                                               r["MinNs"], r["MaxNs"], r["Percentage"]))
+            # (kernel names hold commas - template arguments: quoted)
+            f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                 r["MinNs"], r["MaxNs"], r["Percentage"]))
 
 
 def counters(pattern, kernel_filter):
