@@ -267,6 +267,12 @@ __global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict_
     float *wsh = tile + (FLAT ? 4 * 64 * kFluxV4 : (kFluxT + 1) * kFluxTileStride + 1);
     const int wsh_len = ((n_bins + 3) & ~3) + kFluxCh;
     int *starts = reinterpret_cast<int *>(wsh + wsh_len);       // [64] stream that starts at the block's frame (+ 1)
+    // a row of zeros: the "previous row" of a stream's first frame when the caller hands none over (prev0 == NULL) - the
+    // frame then walks like any other (no select per bin)
+    float *zrow = reinterpret_cast<float *>(starts + 64);
+    const int zrow_len = FLAT ? wsh_len : kFluxTileStride + 1;
+    for (int q = lane; q < zrow_len; q += 64)
+        zrow[q] = 0.0f;
     for (int q = lane; q < wsh_len; q += 64)
         wsh[q] = q + 1 < n_bins ? 1.0f - ((float)(q + 1) / (float)n_bins) : 0.0f;
     // every wave owns a contiguous run of blocks (consecutive blocks share a row, and the stream cursor below moves on
@@ -393,14 +399,16 @@ __global__ __launch_bounds__(64) void onset_flux_kernel(const float *__restrict_
             first = t == 0;
             p0 = first ? prev0 : nullptr;
         }
-        const bool any_first = __ballot(first && live) != 0;
+        // (the select-per-bin form only where a starting frame brings a previous row of its own)
+        const bool any_first = __ballot(first && live && p0 != nullptr) != 0;
+        const bool zero_prev = first && p0 == nullptr;
 
         float fl = 0.0f, en = 0.0f;
         auto walk = [&](const float *cur, const float *prv, int kb, int k0, int k1) {
             if (any_first)
                 flux_walk<true>(cur, prv, first, p0, wsh, kb, k0, k1, n_bins, fl, en);
             else
-                flux_walk<false>(cur, prv, first, p0, wsh, kb, k0, k1, n_bins, fl, en);
+                flux_walk<false>(cur, zero_prev ? zrow : prv, first, p0, wsh, kb, k0, k1, n_bins, fl, en);
         };
         if (FLAT) {
             // float j of the span sits at tile[lead + j]; row r of the block (r = 0: the frame before it) starts n_bins
@@ -1874,7 +1882,9 @@ hipError_t launch_onset_flux(const float *mags, const float *prev0, float *flux,
     const int64_t n_blocks = (n_frames + kFluxT - 1) / kFluxT;
     // the flat form holds a block's 65 rows (+ 3 floats of alignment) in 33 sixteen-byte pieces per lane
     const bool flat = (int64_t)(kFluxT + 1) * n_bins + 3 <= 4 * 64 * kFluxV4;
-    const size_t lds = sizeof(float) * (size_t)((flat ? 4 * 64 * kFluxV4 : (kFluxT + 1) * kFluxTileStride + 1) + ((n_bins + 3) & ~3) + kFluxCh + 64);
+    const int wsh_len = ((n_bins + 3) & ~3) + kFluxCh;
+    const size_t lds = sizeof(float) * (size_t)((flat ? 4 * 64 * kFluxV4 : (kFluxT + 1) * kFluxTileStride + 1) + wsh_len + 64 +
+                                                (flat ? wsh_len : kFluxTileStride + 1));   // image | weights | starts | zero row
     if (lds > 64 * 1024)
         return hipErrorInvalidValue;
     // persistent waves, one per workgroup: four fit a CU's LDS (34 KB each), blocks dealt round robin
