@@ -718,6 +718,67 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
     elapsed = max_over_ranks(elapsed)
     kernel_ms_max = max_over_ranks(kernel_ms)
 
+    # The headline figure is complete here.  Rank 0 keeps the line it would print if nothing below came back (run_multi's
+    # watchdog) and checks rows of its OWN shard against the truth - the end-to-end legs that follow are the first code
+    # of this file that moves bytes between GPUs, and a fault there must not take the measured compute figure with it.
+    total_frames = shard.total_frames
+    achieved = BYTES_PER_FRAME * total_frames / (kernel_ms_max * 1e-3) / 1e9
+    base = None
+    if rank == 0:
+        comp.execute(xd, nf, out)
+        comp.sync()
+        ids = pick_rows(nf, 64, seed=3)
+        local_err = check_rows(x, out[torch.from_numpy(ids).to(out.device)].cpu().numpy(), ids, N_FFT, HOP, "mag")
+        base = {
+            "metric": "STFT frames/s (1024-pt, hop 256, 48 kHz f32)",
+            "value": total_frames * steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size(),
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[3]: {total_samples / SR / 60:.4g} min synthetic 48 kHz corpus "
+                            f"({total_samples} samples, {total_frames} frames), 1024-pt STFT, hop 256, "
+                            f"frame-range sharded over {world} ranks ({nf} frames on rank 0), |X| out",
+                "n_fft": N_FFT, "hop": HOP, "output": "mag", "frames_total": total_frames,
+                "parallelism": f"frame-range shards x{world}; value = compute only, rows stay sharded, "
+                               "no data-path collective",
+                "kernel": comp.kernel,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
+                "kernel_ms": kernel_ms_max, "bytes_per_frame": BYTES_PER_FRAME,
+                "frames_per_launch": nf,
+            },
+            "post_check_local_max_err": local_err,
+            "post_check_max_err": local_err,
+            "post_check_tol": TOL_VS_TRUTH,
+        }
+        if ctx is not None:
+            ctx["partial"] = dict(base, e2e={"error": "the end-to-end legs did not come back (watchdog)"})
+    try:
+        e2e_rec, post_err = _e2e_legs(dist, comp, aa, torch, shard, xd, out, nf, rank, e2e_passes, max_over_ranks, ctx)
+    except Exception as ex:                                       # noqa: BLE001 (reported in the line, never fatal for it)
+        e2e_rec, post_err = {"error": f"{type(ex).__name__}: {ex}"}, None
+    if rank != 0:
+        return None
+    base["e2e"] = e2e_rec
+    if post_err is not None:
+        base["post_check_max_err"] = max(post_err, base["post_check_local_max_err"])
+    return base
+
+
+def _e2e_legs(dist, comp, aa, torch, shard, xd, out, nf, rank, e2e_passes, max_over_ranks, ctx):
+    """configs[3] end to end (rank 0 owns the samples and wants all the rows): serial and overlapped.  Returns the `e2e`
+    record and the post-check error of the gathered rows (None off rank 0)."""
     # ---- (ii) end to end: rank 0 owns the samples and wants all the rows -------------------------
     full = aa.gather_samples(xd, shard, dst=0)                     # untimed: builds rank 0's input
     rows_root = comp.empty(shard.total_frames, comp.cols) if rank == 0 else None
@@ -779,58 +840,26 @@ def run_sharded(dist, comp, world, rank, total_samples, steps, warmup, e2e_passe
     if ctx is not None:
         ctx.update(shard=shard, full=full, out=out, rows_root=rows_root, nf=nf)
     if rank != 0:
-        return None
-    total_frames = shard.total_frames
-    achieved = BYTES_PER_FRAME * total_frames / (kernel_ms_max * 1e-3) / 1e9
-    return {
-        "metric": "STFT frames/s (1024-pt, hop 256, 48 kHz f32)",
-        "value": total_frames * steps / elapsed,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "n_ranks_seen": dist.get_world_size(),
-        "steps": steps,
-        "warmup": warmup,
-        "ms_per_step": elapsed / steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"configs[3]: {total_samples / SR / 60:.4g} min synthetic 48 kHz corpus "
-                        f"({total_samples} samples, {total_frames} frames), 1024-pt STFT, hop 256, "
-                        f"frame-range sharded over {world} ranks ({nf} frames on rank 0), |X| out",
-            "n_fft": N_FFT, "hop": HOP, "output": "mag", "frames_total": total_frames,
-            "parallelism": f"frame-range shards x{world}; value = compute only, rows stay sharded, "
-                           "no data-path collective",
-            "kernel": comp.kernel,
-        },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-            "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
-            "kernel_ms": kernel_ms_max, "bytes_per_frame": BYTES_PER_FRAME,
-            "frames_per_launch": nf,
-        },
-        "e2e": {
-            "what": "rank 0 scatters sample ranges (grouped send/recv), every rank computes, rows "
-                    "gathered unpadded to rank 0; median of %d passes, max over ranks" % e2e_passes,
-            "scatter_ms": r4(e2e[0] * 1e3), "compute_ms": r4(e2e[1] * 1e3), "gather_ms": r4(e2e[2] * 1e3),
-            "serial_total_ms": r4(e2e[3] * 1e3), "serial_frames_per_s": r4(total_frames / e2e[3]),
-            "gather_GBps": r4(total_frames * comp.cols * 4 * (world - 1) / world / e2e[2] / 1e9),
-            # the overlapped form of the same job: scatter k + 1 || compute k || gather k - 1
-            "total_ms": r4(overlapped * 1e3), "frames_per_s": r4(total_frames / overlapped),
-            "overlap": {"pieces_per_rank": E2E_PIECES, "total_ms": r4(overlapped * 1e3),
-                        "speedup_vs_serial": r4(e2e[3] / overlapped),
-                        "post_check_max_err": post_err_overlapped,
-                        # counted, not timed: computes queued with the next piece's scatter / an earlier piece's gather
-                        # posted and not yet waited for (pieces - 1 each when the legs overlap as designed)
-                        "computes_with_scatter_in_flight": sched["scatter_ahead"],
-                        "computes_with_gather_in_flight": sched["gather_behind"],
-                        "how": "aa.overlapped_e2e: batch_isend_irecv per piece, waited for where the data is needed"},
-        },
-        "post_check_max_err": post_err if post_err_overlapped is None else max(post_err, post_err_overlapped),
-        "post_check_tol": TOL_VS_TRUTH,
+        return None, None
+    total_frames, world = shard.total_frames, dist.get_world_size()
+    rec = {
+        "what": "rank 0 scatters sample ranges (grouped send/recv), every rank computes, rows "
+                "gathered unpadded to rank 0; median of %d passes, max over ranks" % e2e_passes,
+        "scatter_ms": r4(e2e[0] * 1e3), "compute_ms": r4(e2e[1] * 1e3), "gather_ms": r4(e2e[2] * 1e3),
+        "serial_total_ms": r4(e2e[3] * 1e3), "serial_frames_per_s": r4(total_frames / e2e[3]),
+        "gather_GBps": r4(total_frames * comp.cols * 4 * (world - 1) / world / e2e[2] / 1e9),
+        # the overlapped form of the same job: scatter k + 1 || compute k || gather k - 1
+        "total_ms": r4(overlapped * 1e3), "frames_per_s": r4(total_frames / overlapped),
+        "overlap": {"pieces_per_rank": E2E_PIECES, "total_ms": r4(overlapped * 1e3),
+                    "speedup_vs_serial": r4(e2e[3] / overlapped),
+                    "post_check_max_err": post_err_overlapped,
+                    # counted, not timed: computes queued with the next piece's scatter / an earlier piece's gather
+                    # posted and not yet waited for (pieces - 1 each when the legs overlap as designed)
+                    "computes_with_scatter_in_flight": sched["scatter_ahead"],
+                    "computes_with_gather_in_flight": sched["gather_behind"],
+                    "how": "aa.overlapped_e2e: batch_isend_irecv per piece, waited for where the data is needed"},
     }
+    return rec, (post_err if post_err_overlapped is None else max(post_err, post_err_overlapped))
 
 
 def run_multi(args):
@@ -875,8 +904,31 @@ def run_multi(args):
     total = int(os.environ.get("AA_BENCH_CORPUS_SAMPLES", SAMPLES_1H))
     ctx = {}
     rc = 0
-    result = run_sharded(dist, comp, world, rank, total, args.steps, args.warmup, ctx=ctx)
-    if transport is not None:
+    # run_sharded under a watchdog: its end-to-end legs are the first code that moves bytes between GPUs; if they never
+    # come back, rank 0 still prints the compute-only line it has held since the timed steps (ctx["partial"])
+    import threading
+
+    box = {}
+
+    def body():
+        try:
+            torch.cuda.set_device(dev_index)                 # (the current device is per thread)
+            box["result"] = run_sharded(dist, comp, world, rank, total, args.steps, args.warmup, ctx=ctx)
+        except BaseException as ex:                          # noqa: BLE001 (re-raised below, on the main thread)
+            box["exc"] = ex
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("AA_BENCH_E2E_TIMEOUT", "420")))
+    hung = th.is_alive()
+    if "exc" in box:
+        raise box["exc"]
+    if hung:
+        print(f"rank {rank}: the sharded run did not come back within its limit", file=sys.stderr, flush=True)
+        if rank != 0 or "partial" not in ctx:
+            os._exit(4 if rank == 0 else 0)
+    result = ctx["partial"] if hung else box.get("result")
+    if transport is not None and not hung:
         transport.close()
     if rank == 0:
         if mode == "ipc":
@@ -889,7 +941,11 @@ def run_multi(args):
         if not result["post_check_max_err"] <= TOL_VS_TRUTH:
             print(f"post-check FAILED: {result['post_check_max_err']}", file=sys.stderr)
             rc = 3
-    if not rehearsal and os.environ.get("AA_BENCH_CABI_LEG", "1") == "1":
+        if "error" in result.get("e2e", {}):
+            print("e2e legs: " + result["e2e"]["error"], file=sys.stderr, flush=True)
+    if hung:
+        os._exit(rc)                                       # the line is out; the legs that hang hold the process group
+    if not rehearsal and "shard" in ctx and os.environ.get("AA_BENCH_CABI_LEG", "1") == "1":
         # The same end-to-end pass on the C-ABI collectives (aa_comm_*: librccl bound by libaa_stft.so,
         # what a Rust / C++ host would call).  Reported on stderr and in the detail file; it runs in
         # a watchdog thread so that a communicator that never forms cannot hold the job.

@@ -95,6 +95,45 @@ def test_bench_sharded_path_over_gloo(tmp_path, world):
     assert res["roofline"]["frames_per_launch"] == frames // world
 
 
+def _worker_failing_legs(rank, world, port, total, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import audio_analyzer_rs_amd as aa
+        import bench
+
+        def broken(*a, **k):
+            raise RuntimeError("link down (test)")
+
+        aa.gather_samples = broken                       # the first call of the end-to-end legs, on every rank
+        ctx = {}
+        res = bench.run_sharded(dist, OracleCompute(), world, rank, total, steps=2, warmup=1, e2e_passes=2, ramp_s=0.0,
+                                ctx=ctx)
+        if rank == 0:
+            json.dump({"res": res, "partial": ctx["partial"]}, open(os.path.join(tmpdir, "result.json"), "w"))
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_line_survives_failing_e2e_legs(tmp_path):
+    """The end-to-end legs are the first code of bench.py that moves bytes between GPUs: when they raise, the line still
+    carries the measured compute-only figure, a post-check of rank 0's own rows and the error; and the line run_multi's
+    watchdog would print if they never came back (ctx["partial"]) is the same line."""
+    total = 3 * 48000
+    mp.spawn(_worker_failing_legs, args=(2, _free_port(), total, str(tmp_path)), nprocs=2, join=True)
+    got = json.load(open(tmp_path / "result.json"))
+    res, partial = got["res"], got["partial"]
+    assert res["value"] > 0 and res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert "link down" in res["e2e"]["error"]
+    assert res["post_check_max_err"] == res["post_check_local_max_err"] <= res["post_check_tol"]
+    assert partial["value"] == res["value"] and "error" in partial["e2e"]
+    assert {k for k in res if k != "e2e"} == {k for k in partial if k != "e2e"}
+
+
 def test_overlap_counts_tell_schedules_apart():
     """aa.overlap_counts on hand-made traces: the designed schedule, the serial one (rejected: not the issue order), and
     a schedule that waits for every gather at once (no rows in flight behind a compute)."""
