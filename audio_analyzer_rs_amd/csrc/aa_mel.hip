@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(64) void tuner_pitches_kernel(
             const int k = lane + 64 * i;
             if (k < n_bins) {
                 rm[i] = mags[t * n_bins + k];
-                rn[i] = eff_floor[t * n_bins + k];
+                if (64 * i + 63 > min_bin && 64 * i < max_bin)    // (wave uniform) the floor is read where peaks may lie
+                    rn[i] = eff_floor[t * n_bins + k];
             }
         }
     };
